@@ -1,0 +1,358 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+Plain-PyTorch fp32 restatement of the reference's SAC/TD3 hot path, used as the
+parity oracle by ``tests/``, by ``__graft_entry__.smoke()`` and by the baseline
+legs of ``bench.py`` (where it is the thing compared against, never the thing
+shipped). Nothing under ``sac-td3-cudagraphs-pytorch_amd/`` may import it.
+
+What it restates (paths relative to the reference checkout):
+
+* ``agents/nets.py:34-49``   orthogonal init / LN ones-zeros        -> ``_reference_init``
+* ``agents/nets.py:52-92``   Critic                                 -> ``QNet``
+* ``agents/nets.py:95-159``  Actor (TD3)                            -> ``DetPolicy``
+* ``agents/nets.py:162-234`` TanhGaussActor (SAC)                   -> ``SquashedGaussPolicy``
+* ``agents/agent.py:54-139`` construction, Adam hyper-parameters    -> ``RefAgent.__init__``
+* ``agents/agent.py:172-181`` predict                               -> ``RefAgent.predict``
+* ``agents/agent.py:183-242`` update_qnets                          -> ``RefAgent.update_qnets``
+* ``agents/agent.py:244-318`` update_actor (+ alpha)                -> ``RefAgent.update_actor``
+* ``agents/agent.py:320-331`` update_targ_nets                      -> ``RefAgent.update_targ_nets``
+* ``orchestrator.py:337-352`` loop body / actor-delay schedule      -> ``RefAgent.iteration``
+
+Pinning status.  The three network classes are checked bit-for-bit against the
+*imported* reference ``agents/nets.py`` by ``tests/golden/make_golden.py`` (run
+in the build container, where ``/root/reference`` exists).  The agent-level
+update logic cannot be pinned the same way: ``agents/agent.py`` needs
+``tensordict``/``torchrl``/``omegaconf``/``wandb`` which are absent, and the
+reference ships no tests or golden vectors -> for that part: PARITY UNPINNED
+(the restatement uses real torch autograd and ``torch.optim.Adam``, so only the
+glue is restated).
+
+Differences from the reference that do not change the arithmetic:
+* no tensordict: the twin critics are two modules under ONE Adam instance
+  (Adam is element-wise, so this equals Adam over the dense-stacked ``[2, ...]``
+  tensors of ``agents/agent.py:106-119``);
+* every random draw can be injected (``eps=...``) so that another implementation
+  can be driven with identical noise.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+LOG_STD_LO, LOG_STD_HI = -5.0, 2.0  # agents/nets.py:13
+HID = 256  # agents/agent.py:56,101 hard-codes (256, 256)
+
+
+@dataclass
+class Hps:
+    """Numeric hyper-parameters read by the hot path (tasks/defaults/{sac,td3}.yml)."""
+    prefer_td3_over_sac: bool = False
+    layer_norm: bool = True
+    actor_lr: float = 3e-4
+    qnets_lr: float = 1e-3
+    log_alpha_lr: float = 1e-3
+    clip_norm: float = 0.0
+    batch_size: int = 256
+    gamma: float = 0.99
+    polyak: float = 0.005
+    bcq_style_targ_mix: bool = False
+    actor_update_delay: int = 2
+    crit_targ_update_freq: int = 1
+    alpha_init: float = 0.2
+    autotune: bool = True
+    actor_noise_std: float = 0.1
+    targ_actor_smoothing: bool = True
+    td3_std: float = 0.2
+    td3_c: float = 0.5
+    segment_len: int = 1
+    num_envs: int = 4
+
+    @staticmethod
+    def sac(**kw) -> "Hps":
+        return Hps(**kw)
+
+    @staticmethod
+    def td3(**kw) -> "Hps":
+        base = dict(prefer_td3_over_sac=True, bcq_style_targ_mix=True, qnets_lr=3e-4)
+        base.update(kw)
+        return Hps(**base)
+
+
+# --------------------------------------------------------------------------- nets
+
+class _Block(nn.Module):
+    def __init__(self, n_in: int, n_out: int, layer_norm: bool, device):
+        super().__init__()
+        self.fc = nn.Linear(n_in, n_out, device=device)
+        self.ln = nn.LayerNorm(n_out, device=device) if layer_norm else nn.Identity()
+
+    def forward(self, x):
+        return torch.relu(self.ln(self.fc(x)))
+
+
+class _Trunk(nn.Module):
+    def __init__(self, n_in: int, layer_norm: bool, device):
+        super().__init__()
+        self.fc_block_1 = _Block(n_in, HID, layer_norm, device)
+        self.fc_block_2 = _Block(HID, HID, layer_norm, device)
+
+    def forward(self, x):
+        return self.fc_block_2(self.fc_block_1(x))
+
+
+def _reference_init(trunk: _Trunk, head: nn.Linear) -> None:
+    # same visiting order as `.apply(init())` on fc_stack then head (nets.py:85-86)
+    for lin in (trunk.fc_block_1.fc, trunk.fc_block_2.fc, head):
+        nn.init.orthogonal_(lin.weight)
+        nn.init.zeros_(lin.bias)
+    for blk in (trunk.fc_block_1, trunk.fc_block_2):
+        if isinstance(blk.ln, nn.LayerNorm):
+            nn.init.ones_(blk.ln.weight)
+            nn.init.zeros_(blk.ln.bias)
+
+
+class QNet(nn.Module):
+    """Q(s, a) -> [B, 1]; state_dict keys equal the reference Critic's."""
+
+    def __init__(self, ob_dim: int, ac_dim: int, layer_norm: bool = True, device="cpu"):
+        super().__init__()
+        self.fc_stack = _Trunk(ob_dim + ac_dim, layer_norm, device)
+        self.head = nn.Linear(HID, 1, device=device)
+        _reference_init(self.fc_stack, self.head)
+
+    def forward(self, ob, ac):
+        return self.head(self.fc_stack(torch.cat([ob, ac], dim=-1)))
+
+
+class DetPolicy(nn.Module):
+    """TD3 policy: tanh(head) * scale + bias; explore adds N(0,1)*scale*sigma."""
+
+    def __init__(self, ob_dim, ac_dim, min_ac, max_ac, exploration_noise: float,
+                 layer_norm: bool = True, device="cpu"):
+        super().__init__()
+        self.fc_stack = _Trunk(ob_dim, layer_norm, device)
+        self.head = nn.Linear(HID, ac_dim, device=device)
+        _reference_init(self.fc_stack, self.head)
+        self.register_buffer("action_scale", (max_ac - min_ac) / 2.0)
+        self.register_buffer("action_bias", (max_ac + min_ac) / 2.0)
+        self.register_buffer("exploration_noise", torch.as_tensor(exploration_noise, device=device))
+
+    def forward(self, ob):
+        return torch.tanh(self.head(self.fc_stack(ob))) * self.action_scale + self.action_bias
+
+    def explore(self, ob, eps=None):
+        ac = self(ob)
+        if eps is None:
+            eps = torch.randn_like(ac)
+        return ac + eps.mul(self.action_scale * self.exploration_noise)
+
+
+class SquashedGaussPolicy(nn.Module):
+    """SAC policy with tanh-bounded log-std in [-5, 2]."""
+
+    def __init__(self, ob_dim, ac_dim, min_ac, max_ac, layer_norm: bool = True, device="cpu"):
+        super().__init__()
+        self.fc_stack = _Trunk(ob_dim, layer_norm, device)
+        self.head = nn.Linear(HID, 2 * ac_dim, device=device)
+        _reference_init(self.fc_stack, self.head)
+        self.register_buffer("action_scale", (max_ac - min_ac) / 2.0)
+        self.register_buffer("action_bias", (max_ac + min_ac) / 2.0)
+
+    def forward(self, ob):
+        mean, raw = self.head(self.fc_stack(ob)).chunk(2, dim=-1)
+        log_std = LOG_STD_LO + 0.5 * (LOG_STD_HI - LOG_STD_LO) * (torch.tanh(raw) + 1)
+        return mean, log_std.exp()
+
+    def get_action(self, ob, eps=None) -> Dict[str, torch.Tensor]:
+        mean, std = self(ob)
+        if eps is None:  # Normal.rsample(): loc + N(0,1) * scale
+            eps = torch.empty_like(mean).normal_()
+        x_t = mean + eps * std
+        y_t = torch.tanh(x_t)
+        action = y_t * self.action_scale + self.action_bias
+        # Normal.log_prob, in torch's operation order
+        log_prob = -((x_t - mean) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))
+        log_prob = log_prob - torch.log(self.action_scale * (1 - y_t.pow(2)) + 1e-6)
+        log_prob = log_prob.sum(1, keepdim=True)
+        mode = torch.tanh(mean) * self.action_scale + self.action_bias
+        return {"sample": action, "log_prob": log_prob, "mode": mode}
+
+
+# --------------------------------------------------------------------------- agent
+
+@dataclass
+class Batch:
+    observations: torch.Tensor
+    actions: torch.Tensor
+    rewards: torch.Tensor            # [B, 1] or [B]
+    next_observations: torch.Tensor
+    dones: torch.Tensor              # bool or {0,1}, [B, 1] or [B]
+
+
+class RefAgent:
+    """Restatement of agents/agent.py:Agent for the update/act path."""
+
+    def __init__(self, ob_dim: int, ac_dim: int, min_ac, max_ac, hps: Hps, device="cpu"):
+        self.hps, self.device = hps, torch.device(device)
+        self.ob_dim, self.ac_dim = ob_dim, ac_dim
+        self.min_ac = torch.as_tensor(min_ac, dtype=torch.float, device=self.device).reshape(-1)
+        self.max_ac = torch.as_tensor(max_ac, dtype=torch.float, device=self.device).reshape(-1)
+        if self.min_ac.numel() == 1:
+            self.min_ac = self.min_ac.expand(ac_dim).clone()
+            self.max_ac = self.max_ac.expand(ac_dim).clone()
+        self.timesteps_so_far = self.actor_updates_so_far = self.qnet_updates_so_far = 0
+
+        def mk_actor():
+            if hps.prefer_td3_over_sac:
+                return DetPolicy(ob_dim, ac_dim, self.min_ac, self.max_ac, hps.actor_noise_std,
+                                 hps.layer_norm, self.device)
+            return SquashedGaussPolicy(ob_dim, ac_dim, self.min_ac, self.max_ac,
+                                       hps.layer_norm, self.device)
+
+        # RNG consumption order of agents/agent.py:61-105: actor, (meta copy: no draws),
+        # actor_detach (a throw-away real init), qnet1, qnet2.
+        self.actor = mk_actor()
+        _ = mk_actor()
+        self.qnets = nn.ModuleList([QNet(ob_dim, ac_dim, hps.layer_norm, self.device) for _ in range(2)])
+        self.actor_target = mk_actor()
+        self.actor_target.load_state_dict(self.actor.state_dict())
+        self.qnets_target = nn.ModuleList([QNet(ob_dim, ac_dim, hps.layer_norm, self.device) for _ in range(2)])
+        self.qnets_target.load_state_dict(self.qnets.state_dict())
+        for p in list(self.actor_target.parameters()) + list(self.qnets_target.parameters()):
+            p.requires_grad_(False)
+
+        self.q_optimizer = torch.optim.Adam(self.qnets.parameters(), lr=hps.qnets_lr)
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=hps.actor_lr)
+        self.log_alpha = None
+        if not hps.prefer_td3_over_sac:
+            self.log_alpha = torch.as_tensor(hps.alpha_init, device=self.device).log()
+            if hps.autotune:
+                self.log_alpha.requires_grad = True
+                self.targ_ent = -ac_dim
+                self.alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=hps.log_alpha_lr)
+        self.trace: Dict[str, torch.Tensor] = {}  # intermediates of the last update, for parity tests
+
+    # -- helpers
+    @property
+    def alpha(self):
+        return None if self.log_alpha is None else self.log_alpha.exp()
+
+    @staticmethod
+    def _twin(qnets, ob, ac):
+        return torch.stack([q(ob, ac) for q in qnets], 0)  # [2, B, 1]
+
+    # -- agents/agent.py:172-181
+    @torch.no_grad()
+    def predict(self, ob, *, explore: bool, eps=None):
+        ob = torch.as_tensor(ob, dtype=torch.float, device=self.device)
+        if self.hps.prefer_td3_over_sac:
+            ac = self.actor.explore(ob, eps) if explore else self.actor(ob)
+        else:
+            ac = self.actor.get_action(ob, eps)["sample" if explore else "mode"]
+        return ac.cpu().numpy()
+
+    # -- agents/agent.py:183-242
+    def update_qnets(self, b: Batch, eps=None) -> Dict[str, torch.Tensor]:
+        h = self.hps
+        self.q_optimizer.zero_grad()
+        with torch.no_grad():
+            if h.prefer_td3_over_sac:
+                logp_next = None
+                pi_next = self.actor_target(b.next_observations)
+                if h.targ_actor_smoothing:
+                    n_ = (torch.randn_like(b.actions) if eps is None else eps) * h.td3_std
+                    n_ = n_.clamp(-h.td3_c, h.td3_c)
+                    a_next = torch.max(torch.min(pi_next + n_, self.max_ac), self.min_ac)
+                else:
+                    a_next = pi_next
+            else:
+                a_next, logp_next, _ = self.actor.get_action(b.next_observations, eps).values()
+            q_t = self._twin(self.qnets_target, b.next_observations, a_next)
+            q_min = q_t.min(0).values
+            q_prime = 0.75 * q_min + 0.25 * q_t.max(0).values if h.bcq_style_targ_mix else q_min
+            if not h.prefer_td3_over_sac:
+                q_prime = q_prime - self.alpha * logp_next
+            not_done = 1.0 - b.dones.flatten().float()
+            targ_q = b.rewards.flatten() + not_done * h.gamma * q_prime.view(-1)
+        q = self._twin(self.qnets, b.observations, b.actions)
+        loss = sum(torch.nn.functional.mse_loss(q[i].view(-1), targ_q) for i in range(2))
+        loss.backward()
+        self.trace.update(next_action=a_next, next_logp=logp_next, q_target=q_t.squeeze(-1), targ_q=targ_q,
+                          q=q.detach().squeeze(-1),
+                          q_grads=[p.grad.clone() for p in self.qnets.parameters()])
+        self.q_optimizer.step()
+        return {"loss/qf_loss": loss.detach()}
+
+    # -- agents/agent.py:244-318
+    def update_actor(self, b: Batch, eps=None, eps_alpha=None) -> Dict[str, torch.Tensor]:
+        h = self.hps
+        self.actor_optimizer.zero_grad()
+        if h.prefer_td3_over_sac:
+            a_pi = self.actor(b.observations)
+        else:
+            a_pi, logp, _ = self.actor.get_action(b.observations, eps).values()
+        for p in self.qnets.parameters():
+            p.requires_grad_(False)  # `.data` in the reference: critics are constants here
+        q_pi = self._twin(self.qnets, b.observations, a_pi)
+        for p in self.qnets.parameters():
+            p.requires_grad_(True)
+        if h.prefer_td3_over_sac:
+            actor_loss = (-q_pi[0]).mean()
+        else:
+            actor_loss = (self.alpha.detach() * logp - q_pi.min(0).values).mean()
+        actor_loss.backward()
+        if h.clip_norm > 0:
+            nn.utils.clip_grad_norm_(self.actor.parameters(), h.clip_norm)
+        self.trace.update(pi_action=a_pi.detach(), q_pi=q_pi.detach().squeeze(-1),
+                          actor_grads=[p.grad.clone() for p in self.actor.parameters()])
+        if not h.prefer_td3_over_sac:
+            self.trace["pi_logp"] = logp.detach()
+        self.actor_optimizer.step()
+        out = {"loss/actor_loss": actor_loss.detach()}
+        if h.prefer_td3_over_sac:
+            return out
+        if h.autotune:
+            self.alpha_optimizer.zero_grad()
+            with torch.no_grad():
+                _, logp2, _ = self.actor.get_action(b.observations, eps_alpha).values()
+            alpha_loss = (self.alpha * (-logp2 - self.targ_ent).detach()).mean()
+            alpha_loss.backward()
+            self.trace["alpha_logp"] = logp2
+            self.alpha_optimizer.step()
+            out["loss/alpha_loss"] = alpha_loss.detach()
+        out["vitals/alpha"] = self.alpha.detach()
+        return out
+
+    # -- agents/agent.py:320-331
+    @torch.no_grad()
+    def update_targ_nets(self):
+        h = self.hps
+        if h.prefer_td3_over_sac or self.qnet_updates_so_far % h.crit_targ_update_freq == 0:
+            for t, p in zip(self.qnets_target.parameters(), self.qnets.parameters()):
+                t.lerp_(p, h.polyak)
+            if h.prefer_td3_over_sac:
+                for t, p in zip(self.actor_target.parameters(), self.actor.parameters()):
+                    t.lerp_(p, h.polyak)
+
+    # -- orchestrator.py:337-352 (one loop iteration after `rb.sample`)
+    def iteration(self, b: Batch, i: int, noise: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """noise: {"critic": eps, "actor": [eps]*delay, "alpha": [eps]*delay} (any may be absent)."""
+        noise = noise or {}
+        out = dict(self.update_qnets(b, noise.get("critic")))
+        self.qnet_updates_so_far += 1
+        if i % (self.hps.actor_update_delay + 1) == 0:
+            for j in range(self.hps.actor_update_delay):
+                ea = noise.get("actor", [None] * (j + 1))[j]
+                el = noise.get("alpha", [None] * (j + 1))[j]
+                out.update(self.update_actor(b, ea, el))
+                self.actor_updates_so_far += 1
+        self.update_targ_nets()
+        return out
+
+    def to_batch(self, obs, act, rew, next_obs, done) -> Batch:
+        f = lambda x: torch.as_tensor(x, dtype=torch.float, device=self.device)
+        return Batch(f(obs), f(act), f(rew), f(next_obs), torch.as_tensor(done, device=self.device))
