@@ -1,0 +1,1034 @@
+// Host side of libsactd3_hip.so: memory plan, kernel sequences, hipGraph capture, C ABI (include/sactd3.h).
+//
+// The kernel sequences restate agents/agent.py:183-331 of the reference in the decomposition that
+// oracle/manual_grads.py documents (and checks against autograd).  One engine owns:
+//   - parameter / gradient / Adam arenas (flat, padded so that every row is float4 aligned),
+//   - the HBM replay ring (one 64-byte-aligned record per transition),
+//   - one batch slot and all activations of one iteration,
+//   - a HIP stream and the captured graphs of update_qnets / update_actor / whole iterations.
+// No torch, no BLAS: the .so depends on libamdhip64 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sactd3.h"
+#include "kernels.h"
+
+static thread_local std::string g_create_error;
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static NetLayout make_layout(int K, int nh) {
+  NetLayout L{};
+  L.K = K; L.ld1 = round_up(K, 4); L.nh = nh;
+  int off = 0;
+  L.W1 = off; off += HID * L.ld1;
+  L.b1 = off; off += HID; L.g1 = off; off += HID; L.be1 = off; off += HID;
+  L.W2 = off; off += HID * HID;
+  L.b2 = off; off += HID; L.g2 = off; off += HID; L.be2 = off; off += HID;
+  L.Wh = off; off += nh * HID;
+  L.bh = off; off += round_up(nh, 4);
+  L.size = off;
+  return L;
+}
+
+// reference (state_dict order, unpadded) <-> arena (padded) for one net
+static int64_t ref_count(const NetLayout& L, int ln) {
+  return (int64_t)HID * L.K + HID + (ln ? 2 * HID : 0) + (int64_t)HID * HID + HID + (ln ? 2 * HID : 0) + (int64_t)L.nh * HID + L.nh;
+}
+static void pack_net(const NetLayout& L, int ln, const float* src, float* dst, bool is_param) {
+  std::fill(dst, dst + L.size, 0.f);
+  if (is_param && !ln) {  // unused LN affine: identity
+    std::fill(dst + L.g1, dst + L.g1 + HID, 1.f);
+    std::fill(dst + L.g2, dst + L.g2 + HID, 1.f);
+  }
+  for (int r = 0; r < HID; ++r) { memcpy(dst + L.W1 + (size_t)r * L.ld1, src, sizeof(float) * L.K); src += L.K; }
+  memcpy(dst + L.b1, src, sizeof(float) * HID); src += HID;
+  if (ln) { memcpy(dst + L.g1, src, sizeof(float) * HID); src += HID; memcpy(dst + L.be1, src, sizeof(float) * HID); src += HID; }
+  memcpy(dst + L.W2, src, sizeof(float) * HID * HID); src += HID * HID;
+  memcpy(dst + L.b2, src, sizeof(float) * HID); src += HID;
+  if (ln) { memcpy(dst + L.g2, src, sizeof(float) * HID); src += HID; memcpy(dst + L.be2, src, sizeof(float) * HID); src += HID; }
+  memcpy(dst + L.Wh, src, sizeof(float) * L.nh * HID); src += (size_t)L.nh * HID;
+  memcpy(dst + L.bh, src, sizeof(float) * L.nh);
+}
+static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst) {
+  for (int r = 0; r < HID; ++r) { memcpy(dst, src + L.W1 + (size_t)r * L.ld1, sizeof(float) * L.K); dst += L.K; }
+  memcpy(dst, src + L.b1, sizeof(float) * HID); dst += HID;
+  if (ln) { memcpy(dst, src + L.g1, sizeof(float) * HID); dst += HID; memcpy(dst, src + L.be1, sizeof(float) * HID); dst += HID; }
+  memcpy(dst, src + L.W2, sizeof(float) * HID * HID); dst += HID * HID;
+  memcpy(dst, src + L.b2, sizeof(float) * HID); dst += HID;
+  if (ln) { memcpy(dst, src + L.g2, sizeof(float) * HID); dst += HID; memcpy(dst, src + L.be2, sizeof(float) * HID); dst += HID; }
+  memcpy(dst, src + L.Wh, sizeof(float) * L.nh * HID); dst += (size_t)L.nh * HID;
+  memcpy(dst, src + L.bh, sizeof(float) * L.nh);
+}
+
+enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_COUNT = 6 };
+static const int NSTAGE = 8;
+
+struct sactd3_engine {
+  sactd3_config cfg{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  std::vector<void*> dev_allocs, host_allocs;
+  std::vector<hipEvent_t> events;
+
+  int o = 0, a = 0, B = 0, ldc = 0, ldo = 0, a4 = 0, nh = 0, ldu = 0, rec_f = 0, rec4 = 0, cx = 0, cn = 0;
+  int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
+  int rpw = 1, nblk = 0;       // row-kernel geometry for B rows
+  int maxn = 0;                // rows accepted by predict
+  int stage_rows = 0;
+  NetLayout La{}, Lc{};
+
+  DevCtl* ctl = nullptr;
+  float *min_ac = nullptr, *max_ac = nullptr, *scale = nullptr, *bias = nullptr;
+  float *Pa = nullptr, *Ta = nullptr, *Ga = nullptr, *Ma = nullptr, *Va = nullptr;
+  float *Pc = nullptr, *Tc = nullptr, *Gc = nullptr, *Mc = nullptr, *Vc = nullptr;
+  float *la = nullptr, *gscale = nullptr;
+  float* ring = nullptr; float* stage_dev = nullptr;
+  float *X = nullptr, *Xn = nullptr, *Xp = nullptr, *rew = nullptr, *done = nullptr;
+  int* idx = nullptr;
+  float *logp_n = nullptr, *logp_pi = nullptr, *logp_al = nullptr, *act_scratch = nullptr;
+  float* eps[SACTD3_NUM_SITES] = {};
+  float *a_z1 = nullptr, *a_h1 = nullptr, *a_st1 = nullptr, *a_z2 = nullptr, *a_h2 = nullptr, *a_st2 = nullptr, *a_tg = nullptr;
+  float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
+  float *c_z1 = nullptr, *c_h1 = nullptr, *c_st1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
+  float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
+  float *part = nullptr, *part_s = nullptr;
+  float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
+  float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
+  float* h_stage[NSTAGE] = {}; hipEvent_t stage_ev[NSTAGE] = {}; int stage_next = 0;
+  float* h_batch = nullptr;                      // pinned [B][rec_f]
+
+  int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
+  hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
+
+  int fail(int code, const char* what, hipError_t he = hipSuccess) {
+    err = what;
+    if (he != hipSuccess) { err += ": "; err += hipGetErrorString(he); }
+    return code;
+  }
+};
+
+#define HIPCHK(call)                                                   \
+  do {                                                                 \
+    hipError_t _he = (call);                                           \
+    if (_he != hipSuccess) return e->fail(SACTD3_EHIP, #call, _he);    \
+  } while (0)
+#define RCCHK(call)                    \
+  do {                                 \
+    int _rc = (call);                  \
+    if (_rc != 0) return _rc;          \
+  } while (0)
+
+template <class T>
+static int dalloc(sactd3_engine* e, T** p, size_t count, bool zero = true) {
+  void* v = nullptr;
+  HIPCHK(hipMalloc(&v, std::max<size_t>(count, 4) * sizeof(T)));
+  e->dev_allocs.push_back(v);
+  if (zero) HIPCHK(hipMemset(v, 0, std::max<size_t>(count, 4) * sizeof(T)));
+  *p = (T*)v;
+  return 0;
+}
+template <class T>
+static int halloc(sactd3_engine* e, T** p, size_t count) {
+  void* v = nullptr;
+  HIPCHK(hipHostMalloc(&v, std::max<size_t>(count, 4) * sizeof(T), hipHostMallocDefault));
+  e->host_allocs.push_back(v);
+  memset(v, 0, std::max<size_t>(count, 4) * sizeof(T));
+  *p = (T*)v;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
+
+static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, const GemmNT& g, int nets) {
+  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  const dim3 grid = tile_grid(tiles, nets);
+  if (pro == 0) hipLaunchKernelGGL((k_gemm_nt<0>), grid, dim3(256), 0, s, g);
+  else if (pro == 1) hipLaunchKernelGGL((k_gemm_nt<1>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((k_gemm_nt<2>), grid, dim3(256), 0, s, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_nn(sactd3_engine* e, hipStream_t s, const GemmNN& g, int nets) {
+  const int tiles = ((g.M + 15) / 16) * ((g.Kout + 15) / 16);
+  hipLaunchKernelGGL(k_gemm_nn, tile_grid(tiles, nets), dim3(256), 0, s, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_tn(sactd3_engine* e, hipStream_t s, const GemmTN& g, int nets) {
+  const int tiles = ((g.N + 15) / 16) * ((g.ldw + 15) / 16);
+  hipLaunchKernelGGL(k_gemm_tn, tile_grid(tiles, nets), dim3(256), 0, s, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// hidden-layer pair of one MLP trunk: z1 = x W1^T + b1 ; z2 = relu(LN(z1)) W2^T + b2
+static int enqueue_trunk(sactd3_engine* e, hipStream_t s, const float* x, int ldx, long x_ns, int K, int M,
+                         const float* P, const NetLayout& L, long p_ns, int nets, float* z1, float* z2,
+                         float* h1_store, float* st1_store, int* tick0, int* tick1) {
+  GemmNT g{};
+  g.A = x; g.lda = ldx; g.a_ns = x_ns; g.Wt = P + L.W1; g.ldw = L.ld1; g.bias = P + L.b1; g.p_ns = p_ns;
+  g.Y = z1; g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K; g.tick0 = tick0; g.tick1 = tick1;
+  RCCHK(launch_nt(e, s, 0, g, nets));
+  GemmNT h{};
+  h.A = z1; h.lda = HID; h.a_ns = (long)M * HID; h.Wt = P + L.W2; h.ldw = HID; h.bias = P + L.b2;
+  h.gamma = P + L.g1; h.beta = P + L.be1; h.p_ns = p_ns;
+  h.Y = z2; h.ldy = HID; h.y_ns = (long)M * HID; h.M = M; h.N = HID; h.K = HID;
+  h.Hout = h1_store; h.h_ns = (long)M * HID; h.stats = st1_store; h.st_ns = 2L * M;
+  RCCHK(launch_nt(e, s, e->cfg.layer_norm ? 1 : 2, h, nets));
+  return 0;
+}
+
+static ActorTail tail_args(sactd3_engine* e, const float* z2, const float* P, int M, int mode, int train,
+                           int site_buf, unsigned site_code, float* dst, int ldd, int dst_off, float* logp, int rpw) {
+  ActorTail t{};
+  t.z2 = z2; t.P = P; t.L = e->La; t.B = M; t.o = e->o; t.a = e->a; t.ln = e->cfg.layer_norm;
+  t.sac = !e->cfg.prefer_td3_over_sac; t.mode = mode; t.train = train; t.rpw = rpw;
+  t.ctl = e->ctl; t.ctr = site_buf == SACTD3_SITE_PREDICT ? &e->ctl->predict_ctr : &e->ctl->noise_ctr;
+  t.site_buf = site_buf; t.site_code = site_code; t.eps = e->eps[site_buf];
+  t.scale = e->scale; t.bias = e->bias; t.min_ac = e->min_ac; t.max_ac = e->max_ac;
+  t.dst = dst; t.ldd = ldd; t.dst_off = dst_off; t.logp = logp;
+  t.h2 = e->a_h2; t.st2 = e->a_st2; t.tg = e->a_tg; t.a4 = e->a4;
+  t.td3_std = e->cfg.td3_std; t.td3_c = e->cfg.td3_c; t.noise_std = e->cfg.actor_noise_std;
+  return t;
+}
+static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
+  const int rows_per_block = 4 * t.rpw;
+  hipLaunchKernelGGL(k_actor_tail, dim3((t.B + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, int identity_len) {
+  GatherArgs g{};
+  g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
+  g.X = (float4*)e->X; g.Xp = (float4*)e->Xp; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
+  g.B = e->B; g.len_override = identity_len;
+  const long threads = (long)e->B * e->rec4;
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static AdamArgs adam_args(sactd3_engine* e, float* p, const float* g, float* m, float* v, long n, const int* t, float lr) {
+  AdamArgs a{};
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.t = t; a.lr = lr;
+  a.b1 = e->cfg.adam_beta1; a.b2 = e->cfg.adam_beta2; a.eps = e->cfg.adam_eps;
+  return a;
+}
+static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
+  const int blocks = (int)std::min<long>(512, (a.n / 4 + 255) / 256);
+  hipLaunchKernelGGL(k_adam, dim3(std::max(blocks, 1)), dim3(256), 0, s, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// agents/agent.py:183-242
+static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sample, float* fused_polyak_targ) {
+  const sactd3_config& c = e->cfg;
+  const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
+  const long BH = (long)B * HID;
+  // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
+  const float* Pact = td3 ? e->Ta : e->Pa;
+  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o, B, Pact, e->La, 0, 1, e->a_z1, e->a_z2, nullptr, nullptr,
+                      &e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr));
+  {
+    const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
+    ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n, e->rpw);
+    RCCHK(launch_tail(e, s, t));
+  }
+  // twin target critics on (s', a') and twin online critics on (s, a)  (agent.py:208-210, 230-232)
+  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o + e->a, B, e->Tc, e->Lc, e->Lc.size, 2, e->t_z1, e->t_z2, nullptr, nullptr, nullptr, nullptr));
+  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, 2, e->c_z1, e->c_z2, e->c_h1, e->c_st1, nullptr, nullptr));
+  {
+    CriticTail t{};
+    t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
+    t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
+    t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.rpw = e->rpw; t.gamma = c.gamma;
+    t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.nblk = e->nblk;
+    hipLaunchKernelGGL(k_critic_tail, dim3(e->nblk, 2), dim3(256), 0, s, t);
+    HIPCHK(hipGetLastError());
+  }
+  {  // dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead
+    GemmTN g{};
+    g.dY = e->c_dz2; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->c_h1; g.ldx = HID; g.x_ns = BH; g.K = HID;
+    g.dW = e->Gc + e->Lc.W2; g.ldw = HID; g.dbias = e->Gc + e->Lc.b2; g.g_ns = e->Lc.size; g.M = B;
+    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
+    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Gc + e->Lc.g2; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Gc + e->Lc.be2; }
+    g.fin_slot[g.nfin] = 2; g.fin_dst[g.nfin++] = e->Gc + e->Lc.Wh;
+    g.part_s = e->part_s; g.fin_s = e->Gc + e->Lc.bh;
+    RCCHK(launch_tn(e, s, g, 2));
+  }
+  {  // dh1 = dz2 W2
+    GemmNN g{};
+    g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
+    g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
+    RCCHK(launch_nn(e, s, g, 2));
+  }
+  {
+    LnBwd l{};
+    l.dh = e->c_dh1; l.dh_ns = BH; l.z = e->c_z1; l.z_ns = BH; l.st = e->c_st1; l.st_ns = 2L * B; l.h = e->c_h1; l.h_ns = BH;
+    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = ln;
+    l.dz = e->c_dz1; l.dz_ns = BH; l.part = e->part; l.nblk = e->nblk;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 2), dim3(256), 0, s, l);
+    HIPCHK(hipGetLastError());
+  }
+  {  // dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
+    GemmTN g{};
+    g.dY = e->c_dz1; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.x_ns = 0; g.K = e->o + e->a;
+    g.dW = e->Gc + e->Lc.W1; g.ldw = e->Lc.ld1; g.dbias = e->Gc + e->Lc.b1; g.g_ns = e->Lc.size; g.M = B;
+    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
+    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Gc + e->Lc.g1; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Gc + e->Lc.be1; }
+    RCCHK(launch_tn(e, s, g, 2));
+  }
+  {
+    AdamArgs a = adam_args(e, e->Pc, e->Gc, e->Mc, e->Vc, 2L * e->Lc.size, &e->ctl->t_q, c.qnets_lr);
+    a.loss_part = e->part_s; a.loss_n = 2 * e->nblk; a.loss_stride = 2; a.loss_off = 1; a.loss_scale = 1.0f / (float)B;
+    a.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS];
+    a.tick = &e->ctl->noise_ctr;
+    a.targ = fused_polyak_targ; a.tau = c.polyak;
+    RCCHK(launch_adam(e, s, a));
+  }
+  return 0;
+}
+
+// agents/agent.py:244-318.  j = index of this actor update inside the iteration (noise sites / streams).
+static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
+  const sactd3_config& c = e->cfg;
+  const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
+  const long BH = (long)B * HID;
+  const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
+  // a_pi, logp = pi(s) with stores for the backward pass
+  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, e->a_h1, e->a_st1, &e->ctl->t_a, nullptr));
+  {
+    ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi, e->rpw);
+    RCCHK(launch_tail(e, s, t));
+  }
+  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
+  RCCHK(enqueue_trunk(e, s, e->Xp, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, nq, e->c_z1, e->c_z2, e->c_h1, e->c_st1, nullptr, nullptr));
+  {
+    ActorQTail t{};
+    t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
+    t.B = B; t.ln = ln; t.sac = !td3; t.rpw = e->rpw; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_s; t.nblk = e->nblk;
+    hipLaunchKernelGGL(k_actorq_tail, dim3(e->nblk), dim3(256), 0, s, t);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    GemmNN g{};
+    g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
+    g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
+    RCCHK(launch_nn(e, s, g, nq));
+  }
+  {
+    LnBwd l{};
+    l.dh = e->c_dh1; l.dh_ns = BH; l.z = e->c_z1; l.z_ns = BH; l.st = e->c_st1; l.st_ns = 2L * B; l.h = e->c_h1; l.h_ns = BH;
+    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = 0;
+    l.dz = e->c_dz1; l.dz_ns = BH; l.part = e->part; l.nblk = e->nblk;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, nq), dim3(256), 0, s, l);
+    HIPCHK(hipGetLastError());
+  }
+  {  // dA_i = dz1_i W1_i[:, o:o+a]
+    GemmNN g{};
+    g.dY = e->c_dz1; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W1; g.ldw = e->Lc.ld1; g.p_ns = e->Lc.size; g.k_off = e->o;
+    g.dX = e->dA; g.ldx = e->a4; g.dx_ns = (long)B * e->a4; g.M = B; g.Kout = e->a;
+    RCCHK(launch_nn(e, s, g, nq));
+  }
+  {
+    ActorHeadBwd h{};
+    h.dA = e->dA; h.dA_ns = (long)B * e->a4; h.ldA = e->a4; h.nq = nq; h.tg = e->a_tg; h.a4 = e->a4; h.eps = e->eps[sb_a];
+    h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.z2 = e->a_z2; h.st2 = e->a_st2; h.h2 = e->a_h2;
+    h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.rpw = e->rpw; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
+    h.part = e->part; h.nblk = e->nblk;
+    hipLaunchKernelGGL(k_actor_head_bwd, dim3(e->nblk), dim3(256), 0, s, h);
+    HIPCHK(hipGetLastError());
+  }
+  {  // head: dWh = du^T h2, dbh
+    GemmTN g{};
+    g.dY = e->a_du; g.ldy = e->ldu; g.N = e->nh; g.X = e->a_h2; g.ldx = HID; g.K = HID;
+    g.dW = e->Ga + e->La.Wh; g.ldw = HID; g.dbias = e->Ga + e->La.bh; g.M = B;
+    RCCHK(launch_tn(e, s, g, 1));
+  }
+  {
+    GemmTN g{};
+    g.dY = e->a_dz2; g.ldy = HID; g.N = HID; g.X = e->a_h1; g.ldx = HID; g.K = HID;
+    g.dW = e->Ga + e->La.W2; g.ldw = HID; g.dbias = e->Ga + e->La.b2; g.M = B;
+    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
+    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Ga + e->La.g2; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Ga + e->La.be2; }
+    RCCHK(launch_tn(e, s, g, 1));
+  }
+  {
+    GemmNN g{};
+    g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
+    RCCHK(launch_nn(e, s, g, 1));
+  }
+  {
+    LnBwd l{};
+    l.dh = e->a_dh1; l.z = e->a_z1; l.st = e->a_st1; l.h = e->a_h1; l.gamma = e->Pa + e->La.g1;
+    l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.nblk = e->nblk;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 1), dim3(256), 0, s, l);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    GemmTN g{};
+    g.dY = e->a_dz1; g.ldy = HID; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.K = e->o;
+    g.dW = e->Ga + e->La.W1; g.ldw = e->La.ld1; g.dbias = e->Ga + e->La.b1; g.M = B;
+    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
+    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Ga + e->La.g1; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Ga + e->La.be1; }
+    RCCHK(launch_tn(e, s, g, 1));
+  }
+  if (c.clip_norm > 0.f) {
+    NormArgs n{e->Ga, (long)e->La.size, c.clip_norm, e->gscale};
+    hipLaunchKernelGGL(k_gradnorm, dim3(1), dim3(1024), 0, s, n);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, &e->ctl->t_a, c.actor_lr);
+    a.gscale = c.clip_norm > 0.f ? e->gscale : nullptr;
+    a.loss_part = e->part_s; a.loss_n = e->nblk; a.loss_stride = 2; a.loss_off = 1; a.loss_scale = 1.0f / (float)B;
+    a.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS];
+    a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
+    RCCHK(launch_adam(e, s, a));
+  }
+  if (!td3) {
+    if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
+      RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, nullptr, nullptr, nullptr, nullptr));
+      ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al, e->rpw);
+      RCCHK(launch_tail(e, s, t));
+    }
+    AlphaArgs al{};
+    al.logp = e->logp_al; al.B = B; al.targ_ent = -(float)e->a; al.autotune = c.autotune; al.la = e->la; al.ctl = e->ctl;
+    al.lr = c.log_alpha_lr; al.b1 = c.adam_beta1; al.b2 = c.adam_beta2; al.eps = c.adam_eps; al.tick = &e->ctl->noise_ctr;
+    hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, al);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// agents/agent.py:328-331
+static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool actor) {
+  PolyakArgs p{};
+  p.tau = e->cfg.polyak;
+  if (critics) { p.t0 = e->Tc; p.p0 = e->Pc; p.n0 = 2L * e->Lc.size; }
+  if (actor) { p.t1 = e->Ta; p.p1 = e->Pa; p.n1 = e->La.size; }
+  const long n = p.n0 + p.n1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_polyak, dim3((unsigned)std::min<long>(512, (n / 4 + 255) / 256)), dim3(256), 0, s, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// orchestrator.py:337-352 as one sequence
+static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak) {
+  const bool td3 = e->cfg.prefer_td3_over_sac;
+  RCCHK(enqueue_gather(e, s, e->ring, -1));
+  // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
+  // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
+  RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr));
+  if (do_actor)
+    for (int j = 0; j < e->cfg.actor_update_delay; ++j) RCCHK(enqueue_update_actor(e, s, j));
+  if (do_polyak && td3) RCCHK(enqueue_polyak(e, s, true, true));
+  return 0;
+}
+
+template <class F>
+static int run_graph(sactd3_engine* e, int which, F&& enqueue) {
+  if (!e->cfg.use_graphs) return enqueue(e->stream);
+  if (!e->graphs[which]) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(e->stream);
+    hipError_t he = hipStreamEndCapture(e->stream, &g);
+    if (rc != 0) { if (g) hipGraphDestroy(g); return rc; }
+    if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipStreamEndCapture", he);
+    size_t n = 0;
+    HIPCHK(hipGraphGetNodes(g, nullptr, &n));
+    e->graph_nodes[which] = (int)n;
+    he = hipGraphInstantiate(&e->graphs[which], g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipGraphInstantiate", he);
+  }
+  HIPCHK(hipGraphLaunch(e->graphs[which], e->stream));
+  return 0;
+}
+
+__global__ void k_set_int1(int* dst, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+static int set_flag(sactd3_engine* e, int* dst, int v) {
+  hipLaunchKernelGGL(k_set_int1, dim3(1), dim3(1), 0, e->stream, dst, v);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// ctl->rb_len and ctl->rb_cursor are adjacent ints
+static int publish_rb_state(sactd3_engine* e) {
+  hipLaunchKernelGGL(k_set_int2, dim3(1), dim3(1), 0, e->stream, &e->ctl->rb_len, (int)e->rb_len, (int)e->rb_cursor);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+#pragma GCC visibility push(default)
+extern "C" {
+
+int sactd3_abi_version(void) { return SACTD3_ABI_VERSION; }
+
+void sactd3_default_config(sactd3_config* c, int td3) {
+  memset(c, 0, sizeof(*c));
+  c->abi_version = SACTD3_ABI_VERSION;
+  c->batch_size = 256; c->rb_capacity = 1000000; c->max_envs = 4;
+  c->prefer_td3_over_sac = td3 ? 1 : 0; c->layer_norm = 1; c->autotune = 1;
+  c->bcq_style_targ_mix = td3 ? 1 : 0; c->targ_actor_smoothing = 1;
+  c->actor_update_delay = 2; c->crit_targ_update_freq = 1; c->use_graphs = 1;
+  c->actor_lr = 3e-4f; c->qnets_lr = td3 ? 3e-4f : 1e-3f; c->log_alpha_lr = 1e-3f;
+  c->gamma = 0.99f; c->polyak = 0.005f; c->alpha_init = 0.2f; c->clip_norm = 0.f;
+  c->td3_std = 0.2f; c->td3_c = 0.5f; c->actor_noise_std = 0.1f;
+  c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1e-8f;
+}
+
+const char* sactd3_last_error(const sactd3_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+void sactd3_destroy(sactd3_engine* e) {
+  if (!e) return;
+  if (e->stream) hipStreamSynchronize(e->stream);
+  for (auto& g : e->graphs) if (g) hipGraphExecDestroy(g);
+  for (auto ev : e->events) hipEventDestroy(ev);
+  for (void* p : e->dev_allocs) hipFree(p);
+  for (void* p : e->host_allocs) hipHostFree(p);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_ac) {
+  const sactd3_config& c = e->cfg;
+  if (c.abi_version != SACTD3_ABI_VERSION) return e->fail(SACTD3_EINVAL, "abi_version mismatch");
+  if (c.ob_dim < 1 || c.ac_dim < 1 || c.ac_dim > 64) return e->fail(SACTD3_EINVAL, "ob_dim >= 1 and 1 <= ac_dim <= 64 required");
+  if (c.batch_size < 1 || c.rb_capacity < 1 || c.max_envs < 1) return e->fail(SACTD3_EINVAL, "batch_size, rb_capacity, max_envs must be positive");
+  if (c.actor_update_delay < 0 || c.crit_targ_update_freq < 1) return e->fail(SACTD3_EINVAL, "actor_update_delay >= 0 and crit_targ_update_freq >= 1 required");
+  if (!min_ac || !max_ac) return e->fail(SACTD3_EINVAL, "min_ac / max_ac required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return e->fail(SACTD3_ENODEV, "no HIP device visible");
+  if (c.device_id < 0 || c.device_id >= ndev) return e->fail(SACTD3_EINVAL, "device_id out of range");
+  HIPCHK(hipSetDevice(c.device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c.device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SACTD3_ALLOW_ANY_ARCH"))
+    return e->fail(SACTD3_ENODEV, "device is not gfx950 (this library carries gfx950 code objects only)");
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+
+  e->o = c.ob_dim; e->a = c.ac_dim; e->B = c.batch_size;
+  const int td3 = c.prefer_td3_over_sac;
+  e->nh = td3 ? e->a : 2 * e->a; e->ldu = round_up(e->nh, 4); e->a4 = round_up(e->a, 4);
+  e->ldc = round_up(e->o + e->a, 4); e->ldo = round_up(e->o, 4);
+  e->cx = e->ldc / 4; e->cn = e->ldo / 4;
+  e->rec_f = round_up(e->ldc + e->ldo + 2, 16); e->rec4 = e->rec_f / 4;
+  e->La = make_layout(e->o, e->nh); e->Lc = make_layout(e->o + e->a, 1);
+  e->nq_actor = td3 ? 1 : 2;
+  e->rpw = std::max(1, (e->B + 255) / 256);
+  e->nblk = (e->B + 4 * e->rpw - 1) / (4 * e->rpw);
+  e->maxn = c.max_envs;
+  e->stage_rows = std::max(c.max_envs, 256);
+  const size_t B = e->B, BH = B * HID;
+
+  RCCHK(dalloc(e, &e->ctl, 1));
+  RCCHK(dalloc(e, &e->min_ac, e->a4)); RCCHK(dalloc(e, &e->max_ac, e->a4));
+  RCCHK(dalloc(e, &e->scale, e->a4)); RCCHK(dalloc(e, &e->bias, e->a4));
+  RCCHK(dalloc(e, &e->Pa, e->La.size)); RCCHK(dalloc(e, &e->Ta, e->La.size)); RCCHK(dalloc(e, &e->Ga, e->La.size));
+  RCCHK(dalloc(e, &e->Ma, e->La.size)); RCCHK(dalloc(e, &e->Va, e->La.size));
+  RCCHK(dalloc(e, &e->Pc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Tc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Gc, 2 * e->Lc.size));
+  RCCHK(dalloc(e, &e->Mc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Vc, 2 * e->Lc.size));
+  RCCHK(dalloc(e, &e->la, 4)); RCCHK(dalloc(e, &e->gscale, 4));
+  RCCHK(dalloc(e, &e->ring, (size_t)c.rb_capacity * e->rec_f, false));
+  RCCHK(dalloc(e, &e->stage_dev, B * e->rec_f));
+  RCCHK(dalloc(e, &e->X, B * e->ldc)); RCCHK(dalloc(e, &e->Xn, B * e->ldc)); RCCHK(dalloc(e, &e->Xp, B * e->ldc));
+  RCCHK(dalloc(e, &e->rew, B)); RCCHK(dalloc(e, &e->done, B)); RCCHK(dalloc(e, &e->idx, B));
+  RCCHK(dalloc(e, &e->logp_n, B)); RCCHK(dalloc(e, &e->logp_pi, B)); RCCHK(dalloc(e, &e->logp_al, B));
+  RCCHK(dalloc(e, &e->act_scratch, B * e->a4));
+  for (int s = 0; s < SACTD3_NUM_SITES; ++s)
+    RCCHK(dalloc(e, &e->eps[s], std::max<size_t>(B, e->maxn) * e->a));
+  RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_st1, 2 * B));
+  RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_st2, 2 * B));
+  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu));
+  RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
+  RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_st1, 4 * B));
+  RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));
+  RCCHK(dalloc(e, &e->t_z1, 2 * BH)); RCCHK(dalloc(e, &e->t_z2, 2 * BH));
+  RCCHK(dalloc(e, &e->q, 2 * B)); RCCHK(dalloc(e, &e->qt, 2 * B)); RCCHK(dalloc(e, &e->y, B)); RCCHK(dalloc(e, &e->q_pi, 2 * B));
+  RCCHK(dalloc(e, &e->dA, 2 * B * e->a4));
+  RCCHK(dalloc(e, &e->part, 2 * (size_t)e->nblk * NSLOT * HID)); RCCHK(dalloc(e, &e->part_s, 2 * (size_t)e->nblk * 2));
+  RCCHK(dalloc(e, &e->p_x, (size_t)e->maxn * e->ldo)); RCCHK(dalloc(e, &e->p_z1, (size_t)e->maxn * HID));
+  RCCHK(dalloc(e, &e->p_z2, (size_t)e->maxn * HID)); RCCHK(dalloc(e, &e->p_act, (size_t)e->maxn * e->a4));
+  RCCHK(halloc(e, &e->h_obs, (size_t)e->maxn * e->ldo)); RCCHK(halloc(e, &e->h_act, (size_t)e->maxn * e->a4));
+  RCCHK(halloc(e, &e->h_batch, B * e->rec_f));
+  for (int i = 0; i < NSTAGE; ++i) {
+    RCCHK(halloc(e, &e->h_stage[i], (size_t)e->stage_rows * e->rec_f));
+    HIPCHK(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
+    e->events.push_back(e->stage_ev[i]);
+  }
+
+  std::vector<float> hb(4 * e->a4, 0.f);
+  for (int j = 0; j < e->a; ++j) {
+    hb[j] = min_ac[j]; hb[e->a4 + j] = max_ac[j];
+    hb[2 * e->a4 + j] = (max_ac[j] - min_ac[j]) / 2.0f;   // agents/nets.py:133-136
+    hb[3 * e->a4 + j] = (max_ac[j] + min_ac[j]) / 2.0f;
+  }
+  HIPCHK(hipMemcpy(e->min_ac, hb.data(), sizeof(float) * e->a4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->max_ac, hb.data() + e->a4, sizeof(float) * e->a4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->scale, hb.data() + 2 * e->a4, sizeof(float) * e->a4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->bias, hb.data() + 3 * e->a4, sizeof(float) * e->a4, hipMemcpyHostToDevice));
+  DevCtl hc{};
+  hc.seed = c.seed;
+  HIPCHK(hipMemcpy(e->ctl, &hc, sizeof(hc), hipMemcpyHostToDevice));
+  const float la0[4] = {logf(c.alpha_init), 0.f, 0.f, 0.f};   // agents/agent.py:128
+  HIPCHK(hipMemcpy(e->la, la0, sizeof(la0), hipMemcpyHostToDevice));
+  // LN gamma = 1 (agents/nets.py:44-47); weights stay 0 until sactd3_set_params
+  {
+    std::vector<float> ha(e->La.size, 0.f), hq(2 * (size_t)e->Lc.size, 0.f);
+    std::fill(ha.begin() + e->La.g1, ha.begin() + e->La.g1 + HID, 1.f);
+    std::fill(ha.begin() + e->La.g2, ha.begin() + e->La.g2 + HID, 1.f);
+    for (int i = 0; i < 2; ++i) {
+      std::fill(hq.begin() + i * e->Lc.size + e->Lc.g1, hq.begin() + i * e->Lc.size + e->Lc.g1 + HID, 1.f);
+      std::fill(hq.begin() + i * e->Lc.size + e->Lc.g2, hq.begin() + i * e->Lc.size + e->Lc.g2 + HID, 1.f);
+    }
+    HIPCHK(hipMemcpy(e->Pa, ha.data(), sizeof(float) * ha.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->Ta, ha.data(), sizeof(float) * ha.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->Pc, hq.data(), sizeof(float) * hq.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->Tc, hq.data(), sizeof(float) * hq.size(), hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+int sactd3_create(const sactd3_config* cfg, const float* min_ac, const float* max_ac, sactd3_engine** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return SACTD3_EINVAL; }
+  *out = nullptr;
+  sactd3_engine* e = new sactd3_engine();
+  e->cfg = *cfg;
+  const int rc = create_impl(e, min_ac, max_ac);
+  if (rc != 0) { g_create_error = e->err; sactd3_destroy(e); return rc; }
+  *out = e;
+  return 0;
+}
+
+// ---- parameters
+static bool which_arena(sactd3_engine* e, int which, float** P, float** M, float** V, const NetLayout** L, int* nets, int** t) {
+  switch (which) {
+    case SACTD3_ACTOR: *P = e->Pa; *M = e->Ma; *V = e->Va; *L = &e->La; *nets = 1; *t = &e->ctl->t_a; return true;
+    case SACTD3_CRITICS: *P = e->Pc; *M = e->Mc; *V = e->Vc; *L = &e->Lc; *nets = 2; *t = &e->ctl->t_q; return true;
+    case SACTD3_ACTOR_TARGET: *P = e->Ta; *M = *V = nullptr; *L = &e->La; *nets = 1; *t = nullptr; return true;
+    case SACTD3_CRITICS_TARGET: *P = e->Tc; *M = *V = nullptr; *L = &e->Lc; *nets = 2; *t = nullptr; return true;
+    default: return false;
+  }
+}
+
+int64_t sactd3_param_count(const sactd3_engine* e, int which) {
+  if (!e) return SACTD3_EINVAL;
+  switch (which) {
+    case SACTD3_ACTOR: case SACTD3_ACTOR_TARGET: return ref_count(e->La, e->cfg.layer_norm);
+    case SACTD3_CRITICS: case SACTD3_CRITICS_TARGET: return 2 * ref_count(e->Lc, e->cfg.layer_norm);
+    case SACTD3_LOG_ALPHA: return 1;
+    default: return SACTD3_EINVAL;
+  }
+}
+
+static int read_arena(sactd3_engine* e, const float* dev, const NetLayout& L, int nets, float* dst) {
+  std::vector<float> h((size_t)nets * L.size);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(h.data(), dev, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+  const int64_t rc = ref_count(L, e->cfg.layer_norm);
+  for (int i = 0; i < nets; ++i) unpack_net(L, e->cfg.layer_norm, h.data() + (size_t)i * L.size, dst + i * rc);
+  return 0;
+}
+static int write_arena(sactd3_engine* e, float* dev, const NetLayout& L, int nets, const float* src, bool is_param) {
+  std::vector<float> h((size_t)nets * L.size);
+  const int64_t rc = ref_count(L, e->cfg.layer_norm);
+  for (int i = 0; i < nets; ++i) pack_net(L, e->cfg.layer_norm, src + i * rc, h.data() + (size_t)i * L.size, is_param);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(dev, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int sactd3_get_params(sactd3_engine* e, int which, float* dst) {
+  if (!e || !dst) return SACTD3_EINVAL;
+  if (which == SACTD3_LOG_ALPHA) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(dst, e->la, sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  float *P, *M, *V; const NetLayout* L; int nets; int* t;
+  if (!which_arena(e, which, &P, &M, &V, &L, &nets, &t)) return e->fail(SACTD3_EINVAL, "bad `which`");
+  return read_arena(e, P, *L, nets, dst);
+}
+
+int sactd3_set_params(sactd3_engine* e, int which, const float* src) {
+  if (!e || !src) return SACTD3_EINVAL;
+  if (which == SACTD3_LOG_ALPHA) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->la, src, sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+  }
+  float *P, *M, *V; const NetLayout* L; int nets; int* t;
+  if (!which_arena(e, which, &P, &M, &V, &L, &nets, &t)) return e->fail(SACTD3_EINVAL, "bad `which`");
+  return write_arena(e, P, *L, nets, src, true);
+}
+
+int sactd3_get_adam_state(sactd3_engine* e, int which, float* m, float* v, int64_t* step) {
+  if (!e) return SACTD3_EINVAL;
+  DevCtl hc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(&hc, e->ctl, sizeof(hc), hipMemcpyDeviceToHost));
+  if (which == SACTD3_LOG_ALPHA) {
+    float h[4];
+    HIPCHK(hipMemcpy(h, e->la, sizeof(h), hipMemcpyDeviceToHost));
+    if (m) *m = h[1];
+    if (v) *v = h[2];
+    if (step) *step = hc.t_l;
+    return 0;
+  }
+  if (which != SACTD3_ACTOR && which != SACTD3_CRITICS) return e->fail(SACTD3_EINVAL, "no optimiser owns this parameter set");
+  float *P, *M, *V; const NetLayout* L; int nets; int* t;
+  which_arena(e, which, &P, &M, &V, &L, &nets, &t);
+  if (m) RCCHK(read_arena(e, M, *L, nets, m));
+  if (v) RCCHK(read_arena(e, V, *L, nets, v));
+  if (step) *step = which == SACTD3_ACTOR ? hc.t_a : hc.t_q;
+  return 0;
+}
+
+int sactd3_set_adam_state(sactd3_engine* e, int which, const float* m, const float* v, int64_t step) {
+  if (!e) return SACTD3_EINVAL;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int st = (int)step;
+  if (which == SACTD3_LOG_ALPHA) {
+    if (m) HIPCHK(hipMemcpy(e->la + 1, m, sizeof(float), hipMemcpyHostToDevice));
+    if (v) HIPCHK(hipMemcpy(e->la + 2, v, sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(&e->ctl->t_l, &st, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+  }
+  if (which != SACTD3_ACTOR && which != SACTD3_CRITICS) return e->fail(SACTD3_EINVAL, "no optimiser owns this parameter set");
+  float *P, *M, *V; const NetLayout* L; int nets; int* t;
+  which_arena(e, which, &P, &M, &V, &L, &nets, &t);
+  if (m) RCCHK(write_arena(e, M, *L, nets, m, false));
+  if (v) RCCHK(write_arena(e, V, *L, nets, v, false));
+  HIPCHK(hipMemcpy(t, &st, sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ---- replay buffer
+static void pack_record(const sactd3_engine* e, float* rec, const float* ob, const float* ac, float rw, const float* nob, uint8_t dn) {
+  memset(rec, 0, sizeof(float) * e->rec_f);
+  memcpy(rec, ob, sizeof(float) * e->o);
+  memcpy(rec + e->o, ac, sizeof(float) * e->a);
+  memcpy(rec + e->ldc, nob, sizeof(float) * e->o);
+  rec[e->ldc + e->ldo] = rw;
+  rec[e->ldc + e->ldo + 1] = dn ? 1.f : 0.f;
+}
+
+int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
+  if (!e || !obs || !act || !rew || !nobs || !dones || n < 0) return e ? e->fail(SACTD3_EINVAL, "rb_extend: bad argument") : SACTD3_EINVAL;
+  const int64_t cap = e->cfg.rb_capacity;
+  int done_rows = 0;
+  while (done_rows < n) {
+    const int chunk = std::min(n - done_rows, e->stage_rows);
+    const int slot = e->stage_next; e->stage_next = (e->stage_next + 1) % NSTAGE;
+    HIPCHK(hipEventSynchronize(e->stage_ev[slot]));
+    float* st = e->h_stage[slot];
+    for (int i = 0; i < chunk; ++i) {
+      const int r = done_rows + i;
+      pack_record(e, st + (size_t)i * e->rec_f, obs + (size_t)r * e->o, act + (size_t)r * e->a, rew[r], nobs + (size_t)r * e->o, dones[r]);
+    }
+    int left = chunk, off = 0;
+    while (left > 0) {   // round-robin writes, wrapping at capacity
+      const int run = (int)std::min<int64_t>(left, cap - e->rb_cursor);
+      HIPCHK(hipMemcpyAsync(e->ring + (size_t)e->rb_cursor * e->rec_f, st + (size_t)off * e->rec_f,
+                            sizeof(float) * (size_t)run * e->rec_f, hipMemcpyHostToDevice, e->stream));
+      e->rb_cursor = (e->rb_cursor + run) % cap;
+      e->rb_len = std::min<int64_t>(cap, e->rb_len + run);
+      left -= run; off += run;
+    }
+    HIPCHK(hipEventRecord(e->stage_ev[slot], e->stream));
+    done_rows += chunk;
+  }
+  return publish_rb_state(e);
+}
+
+int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EINVAL; }
+
+int sactd3_rb_sample(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "rb_sample: buffer is empty");
+  RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
+  hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->sample_ctr, (int*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
+  if (!e || !idx) return SACTD3_EINVAL;
+  if (n != e->B) return e->fail(SACTD3_EINVAL, "rb_sample_with_indices: n must equal batch_size");
+  std::vector<int> h(n);
+  for (int i = 0; i < n; ++i) {
+    if (idx[i] < 0 || idx[i] >= e->rb_len) return e->fail(SACTD3_EINVAL, "rb_sample_with_indices: index out of range");
+    h[i] = (int)idx[i];
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->idx, h.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  RCCHK(set_flag(e, &e->ctl->inject_idx, 1));
+  RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
+  return set_flag(e, &e->ctl->inject_idx, 0);
+}
+
+int sactd3_load_batch(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
+  if (!e || !obs || !act || !rew || !nobs || !dones) return SACTD3_EINVAL;
+  if (n != e->B) return e->fail(SACTD3_EINVAL, "load_batch: n must equal batch_size");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<int> h(n);
+  for (int i = 0; i < n; ++i) {
+    pack_record(e, e->h_batch + (size_t)i * e->rec_f, obs + (size_t)i * e->o, act + (size_t)i * e->a, rew[i], nobs + (size_t)i * e->o, dones[i]);
+    h[i] = i;
+  }
+  HIPCHK(hipMemcpy(e->stage_dev, e->h_batch, sizeof(float) * (size_t)n * e->rec_f, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->idx, h.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  RCCHK(set_flag(e, &e->ctl->inject_idx, 1));
+  RCCHK(enqueue_gather(e, e->stream, e->stage_dev, n));
+  return set_flag(e, &e->ctl->inject_idx, 0);
+}
+
+int sactd3_read_batch(sactd3_engine* e, float* obs, float* act, float* rew, float* nobs, uint8_t* dones, int64_t* idx) {
+  if (!e) return SACTD3_EINVAL;
+  const int B = e->B;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<float> hx((size_t)B * e->ldc), hn((size_t)B * e->ldc), hr(B), hd(B);
+  std::vector<int> hi(B);
+  HIPCHK(hipMemcpy(hx.data(), e->X, sizeof(float) * hx.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hn.data(), e->Xn, sizeof(float) * hn.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hr.data(), e->rew, sizeof(float) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hd.data(), e->done, sizeof(float) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hi.data(), e->idx, sizeof(int) * B, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b) {
+    if (obs) memcpy(obs + (size_t)b * e->o, hx.data() + (size_t)b * e->ldc, sizeof(float) * e->o);
+    if (act) memcpy(act + (size_t)b * e->a, hx.data() + (size_t)b * e->ldc + e->o, sizeof(float) * e->a);
+    if (nobs) memcpy(nobs + (size_t)b * e->o, hn.data() + (size_t)b * e->ldc, sizeof(float) * e->o);
+    if (rew) rew[b] = hr[b];
+    if (dones) dones[b] = hd[b] != 0.f;
+    if (idx) idx[b] = hi[b];
+  }
+  return 0;
+}
+
+int sactd3_rb_fill_synthetic(sactd3_engine* e, int64_t n, uint64_t seed) {
+  if (!e) return SACTD3_EINVAL;
+  if (n < 1 || n > e->cfg.rb_capacity) return e->fail(SACTD3_EINVAL, "rb_fill_synthetic: 1 <= n <= rb_capacity");
+  FillArgs f{(float4*)e->ring, e->rec4, e->cx, e->cn, e->o, e->a, (long)n, seed, e->min_ac, e->max_ac};
+  const long threads = (long)n * e->rec4;
+  hipLaunchKernelGGL(k_rb_fill, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream, f);
+  HIPCHK(hipGetLastError());
+  e->rb_len = std::max<int64_t>(e->rb_len, n);
+  e->rb_cursor = n % e->cfg.rb_capacity;
+  return publish_rb_state(e);
+}
+
+// ---- noise
+int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
+  if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
+  if (n < 1 || n > std::max(e->B, e->maxn)) return e->fail(SACTD3_EINVAL, "set_noise: too many rows");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->eps[site], eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
+  const int one = 1;
+  HIPCHK(hipMemcpy(&e->ctl->inject_eps[site], &one, sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+int sactd3_clear_noise(sactd3_engine* e, int site) {
+  if (!e || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int zeros[8] = {0};
+  if (site < 0) HIPCHK(hipMemcpy(&e->ctl->inject_eps[0], zeros, sizeof(int) * 8, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemcpy(&e->ctl->inject_eps[site], zeros, sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
+  if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES || n < 1 || n > std::max(e->B, e->maxn)) return SACTD3_EINVAL;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(eps, e->eps[site], sizeof(float) * (size_t)n * e->a, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- updates
+int sactd3_update_qnets(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  return run_graph(e, G_Q, [&](hipStream_t s) { return enqueue_update_qnets(e, s, false, nullptr); });
+}
+int sactd3_update_actor(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  return run_graph(e, G_A, [&](hipStream_t s) { return enqueue_update_actor(e, s, 0); });
+}
+int sactd3_update_targ_nets(sactd3_engine* e, int64_t qnet_updates_so_far) {
+  if (!e) return SACTD3_EINVAL;
+  const bool td3 = e->cfg.prefer_td3_over_sac;
+  if (td3 || qnet_updates_so_far % e->cfg.crit_targ_update_freq == 0) return enqueue_polyak(e, e->stream, true, td3);
+  return 0;
+}
+int sactd3_step(sactd3_engine* e, int do_actor) {
+  if (!e) return SACTD3_EINVAL;
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step: buffer is empty");
+  e->qnet_updates += 1;
+  const bool polyak = e->cfg.prefer_td3_over_sac || (e->qnet_updates % e->cfg.crit_targ_update_freq == 0);
+  const bool act = do_actor != 0 && e->cfg.actor_update_delay > 0;
+  const int which = G_STEP00 + (act ? 2 : 0) + (polyak ? 1 : 0);
+  return run_graph(e, which, [&](hipStream_t s) { return enqueue_step(e, s, act, polyak); });
+}
+
+int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions) {
+  if (!e || !obs || !actions) return SACTD3_EINVAL;
+  if (n < 1 || n > e->maxn) return e->fail(SACTD3_EINVAL, "predict: 1 <= n <= max_envs");
+  const bool td3 = e->cfg.prefer_td3_over_sac;
+  HIPCHK(hipStreamSynchronize(e->stream));   // pinned staging is reused
+  for (int i = 0; i < n; ++i) {
+    memset(e->h_obs + (size_t)i * e->ldo, 0, sizeof(float) * e->ldo);
+    memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
+  }
+  HIPCHK(hipMemcpyAsync(e->p_x, e->h_obs, sizeof(float) * (size_t)n * e->ldo, hipMemcpyHostToDevice, e->stream));
+  RCCHK(enqueue_trunk(e, e->stream, e->p_x, e->ldo, 0, e->o, n, e->Pa, e->La, 0, 1, e->p_z1, e->p_z2, nullptr, nullptr, nullptr, nullptr));
+  const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
+  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr, 1);
+  RCCHK(launch_tail(e, e->stream, t));
+  if (explore) {
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(e->h_act, e->p_act, sizeof(float) * (size_t)n * e->a4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; ++i) memcpy(actions + (size_t)i * e->a, e->h_act + (size_t)i * e->a4, sizeof(float) * e->a);
+  return 0;
+}
+
+int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]) {
+  if (!e || !out) return SACTD3_EINVAL;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, e->ctl->metrics, sizeof(float) * SACTD3_NUM_METRICS, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sactd3_sync(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---- introspection
+struct DbgEntry { const char* name; const float* ptr; int64_t n; };
+static std::vector<DbgEntry> dbg_table(sactd3_engine* e) {
+  const int64_t B = e->B, BH = B * HID;
+  return {
+      {"X", e->X, B * e->ldc}, {"Xn", e->Xn, B * e->ldc}, {"Xp", e->Xp, B * e->ldc}, {"rew", e->rew, B}, {"done", e->done, B},
+      {"logp_next", e->logp_n, B}, {"logp_pi", e->logp_pi, B}, {"logp_alpha", e->logp_al, B},
+      {"a_z1", e->a_z1, BH}, {"a_h1", e->a_h1, BH}, {"a_z2", e->a_z2, BH}, {"a_h2", e->a_h2, BH}, {"a_du", e->a_du, B * e->ldu},
+      {"a_dz2", e->a_dz2, BH}, {"a_dh1", e->a_dh1, BH}, {"a_dz1", e->a_dz1, BH},
+      {"c_z1", e->c_z1, 2 * BH}, {"c_h1", e->c_h1, 2 * BH}, {"c_z2", e->c_z2, 2 * BH}, {"c_dz2", e->c_dz2, 2 * BH},
+      {"c_dh1", e->c_dh1, 2 * BH}, {"c_dz1", e->c_dz1, 2 * BH}, {"t_z1", e->t_z1, 2 * BH}, {"t_z2", e->t_z2, 2 * BH},
+      {"q", e->q, 2 * B}, {"q_target", e->qt, 2 * B}, {"targ_q", e->y, B}, {"q_pi", e->q_pi, 2 * B}, {"dA", e->dA, 2 * B * e->a4},
+  };
+}
+const char* sactd3_debug_names(void) {
+  return "X Xn Xp rew done logp_next logp_pi logp_alpha a_z1 a_h1 a_z2 a_h2 a_du a_dz2 a_dh1 a_dz1 c_z1 c_h1 c_z2 c_dz2 c_dh1 c_dz1 "
+         "t_z1 t_z2 q q_target targ_q q_pi dA grad_actor grad_critics";
+}
+int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_t max_floats) {
+  if (!e || !name) return SACTD3_EINVAL;
+  if (!strcmp(name, "grad_actor") || !strcmp(name, "grad_critics")) {   // reference (unpadded) layout
+    const bool act = !strcmp(name, "grad_actor");
+    const int64_t n = sactd3_param_count(e, act ? SACTD3_ACTOR : SACTD3_CRITICS);
+    if (!dst) return n;
+    if (max_floats < n) return e->fail(SACTD3_EINVAL, "debug_read: buffer too small");
+    RCCHK(read_arena(e, act ? e->Ga : e->Gc, act ? e->La : e->Lc, act ? 1 : 2, dst));
+    return n;
+  }
+  for (const DbgEntry& d : dbg_table(e)) {
+    if (strcmp(d.name, name)) continue;
+    if (!dst) return d.n;
+    if (max_floats < d.n) return e->fail(SACTD3_EINVAL, "debug_read: buffer too small");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(dst, d.ptr, sizeof(float) * d.n, hipMemcpyDeviceToHost));
+    return d.n;
+  }
+  return e->fail(SACTD3_EINVAL, "debug_read: unknown buffer name");
+}
+
+int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
+  if (!e) return SACTD3_EINVAL;
+  static const int map[4] = {G_Q, G_A, G_STEP01, G_STEP11};
+  if (which_graph < 0 || which_graph > 3) return SACTD3_EINVAL;
+  int w = map[which_graph];
+  if (!e->graphs[w] && which_graph >= 2) w -= 1;   // the no-Polyak variant, if that is the one in use
+  return e->graph_nodes[w];
+}
+
+int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec) {
+  if (!e || !kernel || !usec || iters < 1) return SACTD3_EINVAL;
+  hipEvent_t t0, t1;
+  HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+  int rc = 0;
+  auto body = [&]() -> int {
+    if (!strcmp(kernel, "gather")) return enqueue_gather(e, e->stream, e->ring, -1);
+    if (!strcmp(kernel, "polyak")) return enqueue_polyak(e, e->stream, true, e->cfg.prefer_td3_over_sac);
+    return e->fail(SACTD3_EINVAL, "time_kernel: unknown kernel (gather | polyak)");
+  };
+  for (int i = 0; i < 3 && rc == 0; ++i) rc = body();   // warm-up
+  if (rc == 0) {
+    hipEventRecord(t0, e->stream);
+    for (int i = 0; i < iters && rc == 0; ++i) rc = body();
+    hipEventRecord(t1, e->stream);
+    hipEventSynchronize(t1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t0, t1);
+    *usec = ms * 1000.f / (float)iters;
+  }
+  hipEventDestroy(t0); hipEventDestroy(t1);
+  return rc;
+}
+
+int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes) {
+  if (!e || !usec || batch < 1 || iters < 1) return SACTD3_EINVAL;
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "gather sweep: buffer is empty");
+  float *X = nullptr, *Xn = nullptr, *Xp = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;
+  const size_t rows = batch;
+  hipError_t he = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (he == hipSuccess) he = hipMalloc(p, bytes); };
+  A((void**)&X, rows * e->ldc * 4); A((void**)&Xn, rows * e->ldc * 4); A((void**)&Xp, rows * e->ldc * 4);
+  A((void**)&rw, rows * 4); A((void**)&dn, rows * 4); A((void**)&ix, rows * 4);
+  int rc = 0;
+  if (he != hipSuccess) rc = e->fail(SACTD3_EHIP, "gather sweep: hipMalloc", he);
+  if (rc == 0) {
+    GatherArgs g{};
+    g.ring = (const float4*)e->ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = ix;
+    g.X = (float4*)X; g.Xp = (float4*)Xp; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
+    const long threads = (long)batch * e->rec4;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    hipEvent_t t0, t1;
+    hipEventCreate(&t0); hipEventCreate(&t1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, e->stream, g);
+    hipEventRecord(t0, e->stream);
+    for (int i = 0; i < iters; ++i) {
+      hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, e->stream, g);
+      hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->sample_ctr, (int*)nullptr);
+    }
+    hipEventRecord(t1, e->stream);
+    he = hipEventSynchronize(t1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t0, t1);
+    *usec = ms * 1000.f / (float)iters;
+    hipEventDestroy(t0); hipEventDestroy(t1);
+    if (he != hipSuccess) rc = e->fail(SACTD3_EHIP, "gather sweep", he);
+    // 2*B*T + 4*B with T = 4*(2o+a+1)+1 bytes
+    if (algo_bytes) *algo_bytes = 2.0 * batch * (4.0 * (2 * e->o + e->a + 1) + 1.0) + 4.0 * batch;
+  }
+  hipFree(X); hipFree(Xn); hipFree(Xp); hipFree(rw); hipFree(dn); hipFree(ix);
+  return rc;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

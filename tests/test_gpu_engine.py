@@ -1,0 +1,418 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP engine, called through the C ABI, against the
+oracle (oracle/sac_td3_ref.py = autograd restatement of the reference; oracle/manual_grads.py = the same maths
+in the engine's kernel decomposition, used to localise a faulty kernel).
+
+Tolerances: fp32 with a different summation order than torch.  Losses / Q-values / targets: rtol 1e-5 + atol 1e-5
+(north_star).  Gradients: atol scaled by the tensor's max (reductions over B).  Post-Adam parameters: see
+tests/helpers.py:assert_params_close.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import replay_ref
+from oracle.manual_grads import ManualAgent
+from oracle.sac_td3_ref import Hps, RefAgent
+from tests.helpers import DIMS, assert_params_close, randomize_ln, synth_transitions
+
+pytestmark = pytest.mark.gpu
+
+P = pytest.importorskip("sac_td3_cudagraphs_pytorch_amd")
+from sac_td3_cudagraphs_pytorch_amd import _lib, schema  # noqa: E402
+
+
+def close(got, want, rtol=1e-5, atol=1e-5, name=""):
+    got = np.asarray(got, np.float32)
+    want = want.detach().cpu().numpy() if hasattr(want, "detach") else np.asarray(want, np.float32)
+    np.testing.assert_allclose(got.reshape(want.shape), want, rtol=rtol, atol=atol, err_msg=name)
+
+
+def gclose(got, want, name=""):
+    want = want.detach().cpu().numpy() if hasattr(want, "detach") else np.asarray(want, np.float32)
+    close(got, want, rtol=2e-4, atol=2e-6 + 1e-5 * float(np.abs(want).max()), name=name)
+
+
+def make_pair(algo, env, B, ln=True, seed=0, use_graphs=True, **hp):
+    o, a, bound = DIMS[env]
+    hps = (Hps.td3 if algo == "td3" else Hps.sac)(layer_norm=ln, batch_size=B, **hp)
+    torch.manual_seed(seed)
+    ref = RefAgent(o, a, [-bound] * a, [bound] * a, hps)
+    randomize_ln(ref)
+    cfg = P.Config.from_hps(hps, o, a, rb_capacity=4096, max_envs=8, seed=seed, use_graphs=use_graphs)
+    eng = P.Engine(cfg, [-bound] * a, [bound] * a)
+    push_params(eng, ref)
+    return ref, eng, (o, a, bound)
+
+
+def flat_actor(ref, module):
+    nh = ref.ac_dim if ref.hps.prefer_td3_over_sac else 2 * ref.ac_dim
+    sd = {k: v for k, v in module.state_dict().items() if k.startswith(("fc_stack", "head"))}
+    return schema.dict_to_flat(sd, ref.ob_dim, nh, ref.hps.layer_norm)
+
+
+def flat_critics(ref, modules):
+    return np.concatenate([schema.dict_to_flat(m.state_dict(), ref.ob_dim + ref.ac_dim, 1, ref.hps.layer_norm) for m in modules])
+
+
+def push_params(eng, ref):
+    eng.set_params(_lib.ACTOR, flat_actor(ref, ref.actor))
+    eng.set_params(_lib.ACTOR_TARGET, flat_actor(ref, ref.actor_target))
+    eng.set_params(_lib.CRITICS, flat_critics(ref, ref.qnets))
+    eng.set_params(_lib.CRITICS_TARGET, flat_critics(ref, ref.qnets_target))
+    if ref.log_alpha is not None:
+        eng.set_params(_lib.LOG_ALPHA, np.array([float(ref.log_alpha)], np.float32))
+
+
+def manual_flat_critic_grads(man, ref):
+    ln = ref.hps.layer_norm
+    return np.concatenate([schema.dict_to_flat(g, ref.ob_dim + ref.ac_dim, 1, ln) for g in man.tr["q_grads"]])
+
+
+# ------------------------------------------------------------------------------------------ replay buffer
+
+def test_params_roundtrip():
+    ref, eng, _ = make_pair("sac", "hopper", 32)
+    for which, want in ((_lib.ACTOR, flat_actor(ref, ref.actor)), (_lib.CRITICS_TARGET, flat_critics(ref, ref.qnets_target))):
+        assert np.array_equal(eng.get_params(which), want)
+    m = np.random.default_rng(0).standard_normal(eng.param_count(_lib.CRITICS)).astype(np.float32)
+    eng.set_adam_state(_lib.CRITICS, m, m * m, 7)
+    m2, v2, st = eng.get_adam_state(_lib.CRITICS)
+    assert np.array_equal(m, m2) and np.array_equal(m * m, v2) and st == 7
+
+
+@pytest.mark.parametrize("env", ["hopper", "halfcheetah", "humanoid"])
+def test_replay_extend_gather_bit_exact(env):
+    o, a, bound = DIMS[env]
+    B, cap = 64, 1000
+    eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=cap, max_envs=8), [-bound] * a, [bound] * a)
+    ring = replay_ref.RingRef(cap, o, a)
+    rng = np.random.default_rng(1)
+    obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(1300, o, a, bound, seed=2)]
+    done[::7] = True
+    assert eng.rb_len() == 0
+    pos = 0
+    for n in (1, 4, 4, 8, 300, 683, 300):  # ragged pushes that wrap the ring once
+        sl = slice(pos, pos + n)
+        eng.rb_extend(obs[sl], act[sl], rew[sl], nobs[sl], done[sl])
+        ring.extend(obs[sl], act[sl], rew[sl], nobs[sl], done[sl])
+        pos += n
+        assert eng.rb_len() == ring.len
+        idx = rng.integers(0, ring.len, B)
+        idx[0], idx[-1] = 0, ring.len - 1
+        eng.rb_sample_with_indices(idx)
+        got, want = eng.read_batch(), ring.gather(idx)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (env, n, k)
+    with pytest.raises(P.EngineError):
+        eng.rb_sample_with_indices(np.full(B, ring.len))  # out of range is refused, not read
+
+
+def test_empty_buffer_refuses_sampling():
+    eng = P.Engine(P.Config(ob_dim=11, ac_dim=3, batch_size=16, rb_capacity=64), [-1] * 3, [1] * 3)
+    with pytest.raises(P.EngineError):
+        eng.rb_sample()
+    with pytest.raises(P.EngineError):
+        eng.step(False)
+
+
+def test_native_index_stream_matches_philox_oracle():
+    o, a, bound = DIMS["hopper"]
+    B, seed = 256, 1234567890123
+    eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=5000, seed=seed), [-1] * a, [1] * a)
+    obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(3000, o, a, bound, seed=3)]
+    eng.rb_extend(obs, act, rew, nobs, done)
+    for draw in range(3):
+        eng.rb_sample()
+        got = eng.read_batch()
+        want_idx = replay_ref.sample_indices(seed, draw, B, 3000)
+        assert np.array_equal(got["index"], want_idx)
+        assert np.array_equal(got["observations"], obs[want_idx]) and np.array_equal(got["rewards"], rew[want_idx])
+        assert np.array_equal(got["actions"], act[want_idx]) and np.array_equal(got["dones"], done[want_idx])
+        assert np.array_equal(got["next_observations"], nobs[want_idx])
+
+
+def test_synthetic_fill_statistics():
+    o, a, bound = DIMS["humanoid"]
+    B = 1024
+    eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=20000), [-bound] * a, [bound] * a)
+    eng.rb_fill_synthetic(20000, seed=9)
+    assert eng.rb_len() == 20000
+    eng.rb_sample()
+    b = eng.read_batch()
+    assert abs(b["observations"].mean()) < 0.01 and abs(b["observations"].std() - 1) < 0.01
+    assert abs(b["next_observations"].std() - 1) < 0.01 and abs(b["rewards"].std() - 1) < 0.1
+    assert b["actions"].min() >= -bound and b["actions"].max() <= bound and abs(b["actions"].mean()) < 0.01
+    assert 0 <= b["dones"].mean() < 0.05
+
+
+# ------------------------------------------------------------------------------------------ single updates
+
+CASES = [("sac", "hopper", 256, True), ("sac", "hopper", 40, False), ("td3", "halfcheetah", 256, True),
+         ("sac", "humanoid", 96, True)]
+
+
+@pytest.mark.parametrize("algo,env,B,ln", CASES)
+def test_update_qnets_intermediates(algo, env, B, ln):
+    ref, eng, (o, a, bound) = make_pair(algo, env, B, ln)
+    man = ManualAgent(ref)
+    obs, act, rew, nobs, done = synth_transitions(B, o, a, bound, seed=3)
+    done[::5] = True
+    eps = torch.randn(B, a, generator=torch.Generator().manual_seed(4))
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.set_noise(_lib.SITE_CRITIC, eps)
+    eng.update_qnets()
+    out = ref.update_qnets(ref.to_batch(obs, act, rew, nobs, done), eps)
+    man.update_qnets(obs, act, rew, nobs, done.float(), eps)
+    H, ldc = 256, (o + a + 3) // 4 * 4
+    Xn = eng.debug_read("Xn").reshape(B, ldc)
+    close(Xn[:, :o], nobs, 0, 0, "s' in the batch slot")
+    close(Xn[:, o:o + a], ref.trace["next_action"], name="next action")
+    if algo == "sac":
+        close(eng.debug_read("logp_next"), ref.trace["next_logp"].reshape(-1), rtol=1e-5, atol=2e-5, name="next logp")
+    close(eng.debug_read("q_target").reshape(2, B), ref.trace["q_target"], name="target Q")
+    close(eng.debug_read("targ_q"), ref.trace["targ_q"], name="Bellman target")
+    close(eng.debug_read("q").reshape(2, B), ref.trace["q"], name="online Q")
+    for i, c in enumerate(man.tr["q_caches"]):
+        close(eng.debug_read("c_z1").reshape(2, B, H)[i], c["z1"], atol=2e-5, name=f"critic{i} z1")
+        close(eng.debug_read("c_h1").reshape(2, B, H)[i], c["h1"], atol=2e-5, name=f"critic{i} h1")
+        close(eng.debug_read("c_z2").reshape(2, B, H)[i], c["z2"], atol=2e-5, name=f"critic{i} z2")
+        gclose(eng.debug_read("c_dz2").reshape(2, B, H)[i], c["dz2"], name=f"critic{i} dz2")
+        gclose(eng.debug_read("c_dh1").reshape(2, B, H)[i], c["dh1"], name=f"critic{i} dh1")
+        gclose(eng.debug_read("c_dz1").reshape(2, B, H)[i], c["dz1"], name=f"critic{i} dz1")
+    got_g = eng.debug_read("grad_critics").reshape(2, -1)
+    want_g = manual_flat_critic_grads(man, ref).reshape(2, -1)
+    keys = schema.net_keys(o + a, 1, ln)
+    for i in range(2):
+        gd, wd = schema.flat_to_dict(got_g[i], o + a, 1, ln), schema.flat_to_dict(want_g[i], o + a, 1, ln)
+        for k, _ in keys:
+            gclose(gd[k], wd[k], name=f"critic{i} grad {k}")
+    close(eng.read_metrics()["loss/qf_loss"], out["loss/qf_loss"], name="qf_loss")
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics after Adam")
+    m, v, step = eng.get_adam_state(_lib.CRITICS)
+    assert step == 1
+
+
+@pytest.mark.parametrize("algo,env,B,ln", CASES)
+def test_update_actor_intermediates(algo, env, B, ln):
+    ref, eng, (o, a, bound) = make_pair(algo, env, B, ln)
+    man = ManualAgent(ref)
+    obs, act, rew, nobs, done = synth_transitions(B, o, a, bound, seed=5)
+    g = torch.Generator().manual_seed(6)
+    e_a, e_l = torch.randn(B, a, generator=g), torch.randn(B, a, generator=g)
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.set_noise(_lib.SITE_ACTOR0, e_a)
+    eng.set_noise(_lib.SITE_ALPHA0, e_l)
+    eng.update_actor()
+    out = ref.update_actor(ref.to_batch(obs, act, rew, nobs, done), e_a, e_l)
+    mo = man.update_actor(obs, e_a, e_l)
+    H, ldc = 256, (o + a + 3) // 4 * 4
+    nq = 1 if algo == "td3" else 2
+    c = man.tr["actor_cache"]
+    close(eng.debug_read("a_h1").reshape(B, H), c["h1"], atol=2e-5, name="actor h1")
+    close(eng.debug_read("a_h2").reshape(B, H), c["h2"], atol=2e-5, name="actor h2")
+    close(eng.debug_read("Xp").reshape(B, ldc)[:, o:o + a], ref.trace["pi_action"], name="pi action")
+    close(eng.debug_read("q_pi").reshape(2, B)[:nq], ref.trace["q_pi"][:nq], name="Q(s, pi)")
+    if algo == "sac":
+        close(eng.debug_read("logp_pi"), ref.trace["pi_logp"].reshape(-1), atol=2e-5, name="pi logp")
+    a4 = (a + 3) // 4 * 4
+    dA = eng.debug_read("dA").reshape(2, B, a4)[:nq, :, :a].sum(0)
+    gclose(dA, man.tr["dA"], name="dLoss/dAction")
+    ldu = (c["u"].shape[1] + 3) // 4 * 4
+    gclose(eng.debug_read("a_du").reshape(B, ldu)[:, :c["u"].shape[1]], man.tr["du"], name="d head out")
+    gclose(eng.debug_read("a_dz2").reshape(B, H), c["dz2"], name="actor dz2")
+    gclose(eng.debug_read("a_dz1").reshape(B, H), c["dz1"], name="actor dz1")
+    nh = a if algo == "td3" else 2 * a
+    got_g = schema.flat_to_dict(eng.debug_read("grad_actor"), o, nh, ln)
+    for (k, _), gr in zip(ref.actor.named_parameters(), ref.trace["actor_grads"]):
+        gclose(got_g[k], gr, name=f"actor grad {k}")
+    met = eng.read_metrics()
+    close(met["loss/actor_loss"], out["loss/actor_loss"], name="actor_loss")
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 1, "actor after Adam")
+    if algo == "sac":
+        close(eng.debug_read("logp_alpha"), ref.trace["alpha_logp"].reshape(-1), rtol=1e-4, atol=1e-3, name="alpha logp")
+        close(met["loss/alpha_loss"], out["loss/alpha_loss"], rtol=1e-4, atol=1e-4, name="alpha_loss")
+        close(met["vitals/alpha"], out["vitals/alpha"], rtol=1e-6, atol=1e-7, name="alpha")
+        close(eng.get_params(_lib.LOG_ALPHA)[0], ref.log_alpha, rtol=1e-6, atol=1e-7, name="log_alpha")
+
+
+def test_clip_norm_and_polyak():
+    ref, eng, (o, a, bound) = make_pair("sac", "hopper", 64, clip_norm=0.05)
+    obs, act, rew, nobs, done = synth_transitions(64, o, a, bound, seed=8)
+    e = torch.randn(64, a)
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.set_noise(_lib.SITE_ACTOR0, e); eng.set_noise(_lib.SITE_ALPHA0, e)
+    eng.update_actor()
+    ref.update_actor(ref.to_batch(obs, act, rew, nobs, done), e, e)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 1, "clipped actor step")
+    before = eng.get_params(_lib.CRITICS_TARGET)
+    ref.qnet_updates_so_far = 1
+    ref.update_targ_nets(); eng.update_targ_nets(1)
+    after = eng.get_params(_lib.CRITICS_TARGET)
+    assert not np.array_equal(before, after)
+    close(after, flat_critics(ref, ref.qnets_target), rtol=1e-6, atol=1e-7, name="Polyak")
+
+
+def test_crit_targ_update_freq_gate():
+    ref, eng, _ = make_pair("sac", "hopper", 16, crit_targ_update_freq=2)
+    t0 = eng.get_params(_lib.CRITICS_TARGET)
+    eng.update_targ_nets(1)
+    assert np.array_equal(eng.get_params(_lib.CRITICS_TARGET), t0)   # 1 % 2 != 0: no update (agent.py:323-324)
+    eng.update_targ_nets(2)
+    assert not np.array_equal(eng.get_params(_lib.CRITICS_TARGET), t0)
+
+
+# ------------------------------------------------------------------------------------------ trajectories
+
+def run_iterations(ref, eng, dims, n_iter, B, data_seed=11):
+    o, a, bound = dims
+    obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(2000, o, a, bound, seed=data_seed)]
+    eng.rb_extend(obs, act, rew, nobs, done)
+    g = torch.Generator().manual_seed(12)
+    rng = np.random.default_rng(13)
+    delay = ref.hps.actor_update_delay
+    logs = []
+    for i in range(n_iter):
+        idx = rng.integers(0, 2000, B)
+        noise = {"critic": torch.randn(B, a, generator=g), "actor": [torch.randn(B, a, generator=g) for _ in range(delay)],
+                 "alpha": [torch.randn(B, a, generator=g) for _ in range(delay)]}
+        b = ref.to_batch(obs[idx], act[idx], rew[idx], nobs[idx], done[idx])
+        want = {k: float(v) for k, v in ref.iteration(b, i, noise).items()}
+        do_actor = i % (delay + 1) == 0
+        eng.set_noise(_lib.SITE_CRITIC, noise["critic"])
+        eng.rb_sample_with_indices(idx)
+        eng.update_qnets()
+        if do_actor:
+            for j in range(delay):
+                eng.set_noise(_lib.SITE_ACTOR0, noise["actor"][j]); eng.set_noise(_lib.SITE_ALPHA0, noise["alpha"][j])
+                eng.update_actor()
+        eng.update_targ_nets(i + 1)
+        got = eng.read_metrics()
+        logs.append((want, got))
+    return logs
+
+
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah")])
+def test_trajectory_api_path(algo, env):
+    """orchestrator.py:337-352 driven call by call for 9 iterations with injected indices and noise."""
+    B = 128
+    ref, eng, dims = make_pair(algo, env, B)
+    logs = run_iterations(ref, eng, dims, 9, B)
+    for i, (want, got) in enumerate(logs):
+        for k, v in want.items():
+            # error growth through the (chaotic) optimisation: 1e-5 at the first steps, widening slowly
+            np.testing.assert_allclose(got[k], v, rtol=1e-5 * (1 + 3 * i), atol=1e-5 * (1 + 3 * i), err_msg=f"iter {i} {k}")
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 9, "critics", max_bad_frac=2e-2)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 6, "actor", max_bad_frac=2e-2)
+    assert_params_close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), ref.hps.qnets_lr, 9, "critic targets")
+
+
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah")])
+def test_graph_replay_equals_eager_launches(algo, env):
+    """the captured hipGraphs and the plain launch sequence are the same kernels: bit-identical state."""
+    B = 64
+    outs = []
+    for use_graphs in (True, False):
+        ref, eng, (o, a, bound) = make_pair(algo, env, B, use_graphs=use_graphs)
+        obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(500, o, a, bound, seed=21)]
+        eng.rb_extend(obs, act, rew, nobs, done)
+        for i in range(6):
+            eng.rb_sample()
+            eng.update_qnets()
+            if i % 3 == 0:
+                eng.update_actor(); eng.update_actor()
+            eng.update_targ_nets(i + 1)
+        outs.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET),
+                     eng.read_metrics(), eng.graph_kernel_count(0)))
+    for x, y in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(x, y)
+    assert outs[0][3] == outs[1][3]
+    assert outs[0][4] > 0 and outs[1][4] == 0
+
+
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah")])
+def test_fused_step_equals_api_sequence(algo, env):
+    """sactd3_step (one graph per iteration) == rb_sample + update_qnets + 2x update_actor + update_targ_nets."""
+    B = 64
+    res = []
+    for fused in (True, False):
+        ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=3)
+        obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(500, o, a, bound, seed=22)]
+        eng.rb_extend(obs, act, rew, nobs, done)
+        for i in range(7):
+            if fused:
+                eng.step(i % 3 == 0)
+            else:
+                eng.rb_sample()
+                eng.update_qnets()
+                if i % 3 == 0:
+                    eng.update_actor(); eng.update_actor()
+                eng.update_targ_nets(i + 1)
+        res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET),
+                    eng.get_params(_lib.ACTOR_TARGET), eng.read_batch()["index"]))
+    # same Philox streams (index: sample counter; noise: site codes 16+j / 32+j and the noise counter), same kernels
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+
+
+def test_native_noise_stream_matches_philox_oracle():
+    ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256, seed=77)
+    obs, act, rew, nobs, done = synth_transitions(256, o, a, bound, seed=1)
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.update_qnets()
+    got = eng.read_noise(_lib.SITE_CRITIC)
+    want = replay_ref.normals(77, 0, 0, 256 * a).reshape(256, a)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+    eng.update_qnets()   # the graph bumped the device-side counter itself: fresh draws
+    got2 = eng.read_noise(_lib.SITE_CRITIC)
+    np.testing.assert_allclose(got2, replay_ref.normals(77, 1, 0, 256 * a).reshape(256, a), rtol=1e-4, atol=2e-5)
+    assert not np.allclose(got, got2)
+
+
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah"), ("sac", "humanoid")])
+def test_predict(algo, env):
+    ref, eng, (o, a, bound) = make_pair(algo, env, 32)
+    for n in (1, 4, 8):
+        obs = torch.randn(n, o, generator=torch.Generator().manual_seed(n))
+        close(eng.predict(obs, explore=False), ref.predict(obs, explore=False), name="exploit")
+        eps = torch.randn(n, a, generator=torch.Generator().manual_seed(100 + n))
+        eng.set_noise(_lib.SITE_PREDICT, eps)
+        close(eng.predict(obs, explore=True), ref.predict(obs, explore=True, eps=eps), name="explore (injected)")
+        eng.clear_noise(_lib.SITE_PREDICT)
+        x, y = eng.predict(obs, explore=True), eng.predict(obs, explore=True)
+        assert not np.array_equal(x, y) and np.isfinite(x).all()
+    with pytest.raises(P.EngineError):
+        eng.predict(torch.zeros(9, o), explore=False)
+
+
+def test_agent_mirror_drives_like_the_reference():
+    """The Python `Agent`/`ReplayBuffer` mirror, used the way orchestrator.py:317-352 uses the reference's."""
+    from types import SimpleNamespace
+    o, a, bound = DIMS["hopper"]
+    hps = SimpleNamespace(**{**Hps.sac(batch_size=64).__dict__, "cudagraphs": True, "rb_capacity": 1000, "seed": 0})
+    rb = P.ReplayBuffer(hps.rb_capacity)
+    torch.manual_seed(0)
+    agent = P.Agent({"ob_shape": (4, o), "ac_shape": (4, a)}, np.full(a, -bound, np.float32), np.full(a, bound, np.float32),
+                    torch.device("cuda:0"), hps, rb)
+    torch.manual_seed(0)
+    ref = RefAgent(o, a, [-bound] * a, [bound] * a, Hps.sac(batch_size=64))
+    assert np.array_equal(agent.engine.get_params(_lib.ACTOR), flat_actor(ref, ref.actor))  # same init as the reference
+    obs, act, rew, nobs, done = synth_transitions(400, o, a, bound, seed=2)
+    for t in range(0, 400, 4):
+        sl = slice(t, t + 4)
+        agent.rb.extend({"observations": obs[sl], "next_observations": nobs[sl], "actions": act[sl],
+                         "rewards": rew[sl].reshape(-1, 1), "terminations": done[sl].reshape(-1, 1), "dones": done[sl].reshape(-1, 1)})
+    assert len(agent.rb) == 400
+    tlog = {}
+    for i in range(6):
+        ac = agent.predict({"observations": obs[:4]}, explore=True)
+        assert ac.shape == (4, a) and ac.dtype == np.float32
+        batch = agent.rb.sample(hps.batch_size)
+        tlog.update(agent.update_qnets(batch)); agent.qnet_updates_so_far += 1
+        if i % (hps.actor_update_delay + 1) == 0:
+            for _ in range(hps.actor_update_delay):
+                tlog.update(agent.update_actor(batch)); agent.actor_updates_so_far += 1
+        agent.update_targ_nets()
+    vals = {k: float(v) for k, v in tlog.items()}
+    assert set(vals) == {"loss/qf_loss", "loss/actor_loss", "loss/alpha_loss", "vitals/alpha"}
+    assert all(np.isfinite(v) for v in vals.values())
+    assert batch["observations"].shape == (64, o) and batch["dones"].shape == (64, 1)
