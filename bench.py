@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gradient-steps/s of the SAC hot path (BASELINE.json configs[1]: SAC Hopper-v4, batch 256,
+hipGraph-captured update step on 1x MI355X), seeds sharded one per GPU for --gpus N (replicas only, no collective).
+
+One "step" = one loop iteration of the reference's orchestrator.py:337-352 on synthetic transitions already
+resident in HBM: replay index draw + gather, critic update, (every 3rd iteration) 2x actor+alpha update on the
+same batch, Polyak.  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hopper_sac|halfcheetah_td3|humanoid_sac]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # SURVEY.md section 8d / BASELINE.md section 3
+    "hopper_sac": dict(env="Hopper-v4", o=11, a=3, bound=1.0, td3=False, batch=256, rows=100_000, capacity=1_000_000),
+    "halfcheetah_td3": dict(env="HalfCheetah-v4", o=17, a=6, bound=1.0, td3=True, batch=256, rows=100_000, capacity=1_000_000),
+    "humanoid_sac": dict(env="Humanoid-v4", o=376, a=17, bound=0.4, td3=False, batch=1024, rows=1_000_000, capacity=1_000_000),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def gather_algo_bytes(o, a, batch):
+    """2*B*T + 4*B, T = 4*(2o+a+1)+1 (s, a, r, s', one done byte; read once + write once; int32 index)."""
+    return 2 * batch * (4 * (2 * o + a + 1) + 1) + 4 * batch
+
+
+def make_engine(w, seed, device_id):
+    import torch
+    import sac_td3_cudagraphs_pytorch_amd as pkg
+    from sac_td3_cudagraphs_pytorch_amd import schema
+    cfg = pkg.Config(ob_dim=w["o"], ac_dim=w["a"], batch_size=w["batch"], rb_capacity=w["capacity"], max_envs=4,
+                     prefer_td3_over_sac=w["td3"], bcq_style_targ_mix=w["td3"], qnets_lr=3e-4 if w["td3"] else 1e-3,
+                     seed=seed, device_id=device_id)
+    eng = pkg.Engine(cfg, [-w["bound"]] * w["a"], [w["bound"]] * w["a"])
+    torch.manual_seed(seed)  # reference init (agents/nets.py:34-49) under the run's seed
+    actor, critics = schema.reference_initial_params(w["o"], w["a"], w["td3"], True)
+    for which, flat in ((0, actor), (2, actor), (1, critics), (3, critics)):
+        eng.set_params(which, flat)
+    eng.rb_fill_synthetic(w["rows"], seed=0)  # data seed 0
+    eng.sync()
+    return eng
+
+
+def oracle_rate(w, device, seconds, threads=None):
+    """iterations/s of the plain-torch restatement (oracle) on `device`: the reference's CPU / eager-ROCm path."""
+    import torch
+    from oracle.sac_td3_ref import Hps, RefAgent
+    if threads:
+        torch.set_num_threads(threads)
+    o, a, B = w["o"], w["a"], w["batch"]
+    hps = (Hps.td3 if w["td3"] else Hps.sac)(batch_size=B)
+    torch.manual_seed(0)
+    ag = RefAgent(o, a, [-w["bound"]] * a, [w["bound"]] * a, hps, device=device)
+    n = min(w["rows"], 100_000)
+    g = torch.Generator().manual_seed(0)
+    data = [torch.randn(n, o, generator=g), (torch.rand(n, a, generator=g) * 2 - 1) * w["bound"], torch.randn(n, generator=g),
+            torch.randn(n, o, generator=g), torch.rand(n, generator=g) < 0.01]
+    data = [d.to(device) for d in data]
+    sync = (lambda: torch.cuda.synchronize()) if str(device).startswith("cuda") else (lambda: None)
+
+    def one(i):
+        idx = torch.randint(0, n, (B,), device=device)
+        b = ag.to_batch(*[d[idx] for d in data])
+        ag.iteration(b, i)
+
+    for i in range(6):
+        one(i)
+    sync()
+    t0, i = time.perf_counter(), 0
+    while True:
+        one(i)
+        i += 1
+        if i % 3 == 0:
+            sync()
+            if time.perf_counter() - t0 >= seconds:
+                break
+    sync()
+    return i / (time.perf_counter() - t0), i
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--workload", default="hopper_sac", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-baselines", action="store_true")
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    eng = make_engine(w, seed=rank, device_id=local)  # seed = GPU index, one independent learner per GPU
+    delay = 2
+    it = 0
+    for _ in range(args.warmup):
+        eng.step(it % (delay + 1) == 0)
+        it += 1
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(it % (delay + 1) == 0)
+        it += 1
+    eng.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank defines the job's time
+        dt = float(t.item())
+        dist.barrier()
+    metrics = eng.read_metrics()
+
+    if rank == 0:
+        out = {
+            "metric": "gradient-steps/sec (SAC, batch=256) at 1 GPU + 8-seed node; replay HBM GB/s",
+            "value": world * args.steps / dt, "unit": "gradient-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{'TD3' if w['td3'] else 'SAC'} {w['env']} batch={w['batch']}, 2x256 MLP + LayerNorm, "
+                                   f"{w['rows']} rows resident in a {w['capacity']}-row HBM replay ring, "
+                                   "one hipGraph launch per iteration (1 critic update, 2 actor+alpha updates every 3rd, Polyak)",
+                       "parallelism": f"{world} independent seeds, one per GPU, no collective"},
+            "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
+            "final_metrics": metrics,
+        }
+        # roofline of the replay gather (the path's HBM-bound kernel; north_star's "replay HBM GB/s"):
+        # algorithmic bytes per launch / average launch duration from HIP events on the engine's stream
+        us = eng.time_kernel("gather", 2000)
+        ab = gather_algo_bytes(w["o"], w["a"], w["batch"])
+        out["roofline"] = {"kernel": "k_gather", "bound": "hbm", "achieved": ab / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ab / us * 1e-3 / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": ab, "avg_launch_us": us}
+        if world == 1 and not args.no_baselines:
+            # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
+            sweep = {}
+            for bs in (256, 4096, 65536):
+                us_b, by = eng.time_gather_sweep(bs, 200 if bs < 65536 else 50)
+                sweep[str(bs)] = {"us": us_b, "GB/s": by / us_b * 1e-3}
+            out["gather_batch_sweep"] = sweep
+            eng.close()
+            v, n = oracle_rate(w, "cpu", args.cpu_seconds)
+            out["cpu_baseline"] = {"value": v, "unit": "gradient-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"{n} iterations of the same workload through oracle/sac_td3_ref.py (plain PyTorch CPU eager)"}
+            v, n = oracle_rate(w, "cuda", 6.0)
+            out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
+                                          "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
+            out["speedup_vs_eager_rocm"] = out["value"] / v
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,7 +80,7 @@ struct sactd3_engine {
 
   int o = 0, a = 0, B = 0, ldc = 0, ldo = 0, a4 = 0, nh = 0, ldu = 0, rec_f = 0, rec4 = 0, cx = 0, cn = 0;
   int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
-  int rpw = 1, nblk = 0;       // row-kernel geometry for B rows
+  int nblk = 0;                // row-kernel blocks (16 rows each) for B rows
   int maxn = 0;                // rows accepted by predict
   int stage_rows = 0;
   NetLayout La{}, Lc{};
@@ -95,9 +95,9 @@ struct sactd3_engine {
   int* idx = nullptr;
   float *logp_n = nullptr, *logp_pi = nullptr, *logp_al = nullptr, *act_scratch = nullptr;
   float* eps[SACTD3_NUM_SITES] = {};
-  float *a_z1 = nullptr, *a_h1 = nullptr, *a_st1 = nullptr, *a_z2 = nullptr, *a_h2 = nullptr, *a_st2 = nullptr, *a_tg = nullptr;
+  float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
-  float *c_z1 = nullptr, *c_h1 = nullptr, *c_st1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
+  float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
   float *part = nullptr, *part_s = nullptr;
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
@@ -148,61 +148,71 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 // ------------------------------------------------------------------------------------------------ launches
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
-static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, const GemmNT& g, int nets) {
-  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
-  const dim3 grid = tile_grid(tiles, nets);
-  if (pro == 0) hipLaunchKernelGGL((k_gemm_nt<0>), grid, dim3(256), 0, s, g);
-  else if (pro == 1) hipLaunchKernelGGL((k_gemm_nt<1>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((k_gemm_nt<2>), grid, dim3(256), 0, s, g);
+static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const NtArgs& g, int nets) {
+  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.N + 63) / 64)), 1, (unsigned)nets);
+  if (fuse1) {
+    if (pro == 1) hipLaunchKernelGGL((k_nt<1, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_nt<2, true>), grid, dim3(256), 0, s, g);
+  } else {
+    if (pro == 0) hipLaunchKernelGGL((k_nt<0, false>), grid, dim3(256), 0, s, g);
+    else if (pro == 1) hipLaunchKernelGGL((k_nt<1, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_nt<2, false>), grid, dim3(256), 0, s, g);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_nn(sactd3_engine* e, hipStream_t s, const GemmNN& g, int nets) {
-  const int tiles = ((g.M + 15) / 16) * ((g.Kout + 15) / 16);
-  hipLaunchKernelGGL(k_gemm_nn, tile_grid(tiles, nets), dim3(256), 0, s, g);
+static int launch_nn(sactd3_engine* e, hipStream_t s, const NnArgs& g, int nets) {
+  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 63) / 64)), 1, (unsigned)nets);
+  hipLaunchKernelGGL(k_nn, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_tn(sactd3_engine* e, hipStream_t s, const GemmTN& g, int nets) {
-  const int tiles = ((g.N + 15) / 16) * ((g.ldw + 15) / 16);
-  hipLaunchKernelGGL(k_gemm_tn, tile_grid(tiles, nets), dim3(256), 0, s, g);
+static int launch_tn(sactd3_engine* e, hipStream_t s, const TnArgs& g, int nets) {
+  const dim3 grid((unsigned)(((g.N + 15) / 16) * ((g.ldw + 63) / 64)), 1, (unsigned)nets);
+  hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// hidden-layer pair of one MLP trunk: z1 = x W1^T + b1 ; z2 = relu(LN(z1)) W2^T + b2
+// The two hidden layers of one MLP trunk: z2 = relu(LN(x W1^T + b1)) W2^T + b2.  One kernel when the input is
+// narrow (first layer recomputed per column strip), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
+struct TrunkStore { float* xh; float* h; float* rstd; };
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, const float* x, int ldx, long x_ns, int K, int M,
                          const float* P, const NetLayout& L, long p_ns, int nets, float* z1, float* z2,
-                         float* h1_store, float* st1_store, int* tick0, int* tick1) {
-  GemmNT g{};
+                         TrunkStore st, int* tick0, int* tick1) {
+  const int pro = e->cfg.layer_norm ? 1 : 2;
+  NtArgs h{};
+  h.Wt = P + L.W2; h.ldw = HID; h.bias = P + L.b2; h.gamma = P + L.g1; h.beta = P + L.be1; h.p_ns = p_ns;
+  h.Y = z2; h.ldy = HID; h.y_ns = (long)M * HID; h.M = M; h.N = HID; h.K = HID;
+  h.xh_out = st.xh; h.h_out = st.h; h.rstd_out = st.rstd; h.act_ns = (long)M * HID;
+  if (K <= 64) {
+    h.X = x; h.ldx = ldx; h.x_ns = x_ns; h.K1 = K; h.W1 = P + L.W1; h.ldw1 = L.ld1; h.b1 = P + L.b1;
+    h.tick0 = tick0; h.tick1 = tick1;
+    return launch_nt(e, s, pro, true, h, nets);
+  }
+  NtArgs g{};
   g.A = x; g.lda = ldx; g.a_ns = x_ns; g.Wt = P + L.W1; g.ldw = L.ld1; g.bias = P + L.b1; g.p_ns = p_ns;
   g.Y = z1; g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K; g.tick0 = tick0; g.tick1 = tick1;
-  RCCHK(launch_nt(e, s, 0, g, nets));
-  GemmNT h{};
-  h.A = z1; h.lda = HID; h.a_ns = (long)M * HID; h.Wt = P + L.W2; h.ldw = HID; h.bias = P + L.b2;
-  h.gamma = P + L.g1; h.beta = P + L.be1; h.p_ns = p_ns;
-  h.Y = z2; h.ldy = HID; h.y_ns = (long)M * HID; h.M = M; h.N = HID; h.K = HID;
-  h.Hout = h1_store; h.h_ns = (long)M * HID; h.stats = st1_store; h.st_ns = 2L * M;
-  RCCHK(launch_nt(e, s, e->cfg.layer_norm ? 1 : 2, h, nets));
-  return 0;
+  RCCHK(launch_nt(e, s, 0, false, g, nets));
+  h.A = z1; h.lda = HID; h.a_ns = (long)M * HID;
+  return launch_nt(e, s, pro, false, h, nets);
 }
 
 static ActorTail tail_args(sactd3_engine* e, const float* z2, const float* P, int M, int mode, int train,
-                           int site_buf, unsigned site_code, float* dst, int ldd, int dst_off, float* logp, int rpw) {
+                           int site_buf, unsigned site_code, float* dst, int ldd, int dst_off, float* logp) {
   ActorTail t{};
   t.z2 = z2; t.P = P; t.L = e->La; t.B = M; t.o = e->o; t.a = e->a; t.ln = e->cfg.layer_norm;
-  t.sac = !e->cfg.prefer_td3_over_sac; t.mode = mode; t.train = train; t.rpw = rpw;
+  t.sac = !e->cfg.prefer_td3_over_sac; t.mode = mode; t.train = train;
   t.ctl = e->ctl; t.ctr = site_buf == SACTD3_SITE_PREDICT ? &e->ctl->predict_ctr : &e->ctl->noise_ctr;
   t.site_buf = site_buf; t.site_code = site_code; t.eps = e->eps[site_buf];
   t.scale = e->scale; t.bias = e->bias; t.min_ac = e->min_ac; t.max_ac = e->max_ac;
   t.dst = dst; t.ldd = ldd; t.dst_off = dst_off; t.logp = logp;
-  t.h2 = e->a_h2; t.st2 = e->a_st2; t.tg = e->a_tg; t.a4 = e->a4;
+  t.h2 = e->a_h2; t.xh2 = e->a_xh2; t.rstd2 = e->a_rs2; t.tg = e->a_tg; t.a4 = e->a4;
   t.td3_std = e->cfg.td3_std; t.td3_c = e->cfg.td3_c; t.noise_std = e->cfg.actor_noise_std;
   return t;
 }
 static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
-  const int rows_per_block = 4 * t.rpw;
-  hipLaunchKernelGGL(k_actor_tail, dim3((t.B + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_actor_tail, dim3((t.B + 15) / 16), dim3(256), 0, s, t);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -210,7 +220,7 @@ static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
 static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, int identity_len) {
   GatherArgs g{};
   g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
-  g.X = (float4*)e->X; g.Xp = (float4*)e->Xp; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
+  g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
   g.B = e->B; g.len_override = identity_len;
   const long threads = (long)e->B * e->rec4;
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, g);
@@ -236,29 +246,31 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
+  const TrunkStore none{nullptr, nullptr, nullptr};
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
-  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o, B, Pact, e->La, 0, 1, e->a_z1, e->a_z2, nullptr, nullptr,
+  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o, B, Pact, e->La, 0, 1, e->a_z1, e->a_z2, none,
                       &e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr));
   {
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
-    ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n, e->rpw);
+    ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
     RCCHK(launch_tail(e, s, t));
   }
   // twin target critics on (s', a') and twin online critics on (s, a)  (agent.py:208-210, 230-232)
-  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o + e->a, B, e->Tc, e->Lc, e->Lc.size, 2, e->t_z1, e->t_z2, nullptr, nullptr, nullptr, nullptr));
-  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, 2, e->c_z1, e->c_z2, e->c_h1, e->c_st1, nullptr, nullptr));
+  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o + e->a, B, e->Tc, e->Lc, e->Lc.size, 2, e->t_z1, e->t_z2, none, nullptr, nullptr));
+  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, 2, e->c_z1, e->c_z2,
+                      TrunkStore{e->c_xh1, e->c_h1, e->c_rs1}, nullptr, nullptr));
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
     t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
-    t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.rpw = e->rpw; t.gamma = c.gamma;
+    t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.nblk = e->nblk;
     hipLaunchKernelGGL(k_critic_tail, dim3(e->nblk, 2), dim3(256), 0, s, t);
     HIPCHK(hipGetLastError());
   }
   {  // dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead
-    GemmTN g{};
+    TnArgs g{};
     g.dY = e->c_dz2; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->c_h1; g.ldx = HID; g.x_ns = BH; g.K = HID;
     g.dW = e->Gc + e->Lc.W2; g.ldw = HID; g.dbias = e->Gc + e->Lc.b2; g.g_ns = e->Lc.size; g.M = B;
     g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
@@ -268,21 +280,21 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
     RCCHK(launch_tn(e, s, g, 2));
   }
   {  // dh1 = dz2 W2
-    GemmNN g{};
+    NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, g, 2));
   }
   {
     LnBwd l{};
-    l.dh = e->c_dh1; l.dh_ns = BH; l.z = e->c_z1; l.z_ns = BH; l.st = e->c_st1; l.st_ns = 2L * B; l.h = e->c_h1; l.h_ns = BH;
-    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = ln;
-    l.dz = e->c_dz1; l.dz_ns = BH; l.part = e->part; l.nblk = e->nblk;
+    l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
+    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = ln;
+    l.dz = e->c_dz1; l.part = e->part; l.nblk = e->nblk;
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 2), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {  // dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
-    GemmTN g{};
+    TnArgs g{};
     g.dY = e->c_dz1; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.x_ns = 0; g.K = e->o + e->a;
     g.dW = e->Gc + e->Lc.W1; g.ldw = e->Lc.ld1; g.dbias = e->Gc + e->Lc.b1; g.g_ns = e->Lc.size; g.M = B;
     g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
@@ -300,43 +312,47 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
   return 0;
 }
 
-// agents/agent.py:244-318.  j = index of this actor update inside the iteration (noise sites / streams).
+// agents/agent.py:244-318.  j = index of this actor update inside the iteration (selects the noise buffers).
 static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
+  const TrunkStore none{nullptr, nullptr, nullptr};
   // a_pi, logp = pi(s) with stores for the backward pass
-  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, e->a_h1, e->a_st1, &e->ctl->t_a, nullptr));
+  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2,
+                      TrunkStore{e->a_xh1, e->a_h1, e->a_rs1}, &e->ctl->t_a, nullptr));
   {
-    ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi, e->rpw);
+    ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+    t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
     RCCHK(launch_tail(e, s, t));
   }
   // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
-  RCCHK(enqueue_trunk(e, s, e->Xp, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, nq, e->c_z1, e->c_z2, e->c_h1, e->c_st1, nullptr, nullptr));
+  RCCHK(enqueue_trunk(e, s, e->Xp, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, nq, e->c_z1, e->c_z2,
+                      TrunkStore{e->c_xh1, e->c_h1, e->c_rs1}, nullptr, nullptr));
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
-    t.B = B; t.ln = ln; t.sac = !td3; t.rpw = e->rpw; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_s; t.nblk = e->nblk;
+    t.B = B; t.ln = ln; t.sac = !td3; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_s; t.nblk = e->nblk;
     hipLaunchKernelGGL(k_actorq_tail, dim3(e->nblk), dim3(256), 0, s, t);
     HIPCHK(hipGetLastError());
   }
   {
-    GemmNN g{};
+    NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, g, nq));
   }
   {
     LnBwd l{};
-    l.dh = e->c_dh1; l.dh_ns = BH; l.z = e->c_z1; l.z_ns = BH; l.st = e->c_st1; l.st_ns = 2L * B; l.h = e->c_h1; l.h_ns = BH;
-    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = 0;
-    l.dz = e->c_dz1; l.dz_ns = BH; l.part = e->part; l.nblk = e->nblk;
+    l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
+    l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = 0;
+    l.dz = e->c_dz1; l.part = e->part; l.nblk = e->nblk;
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, nq), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {  // dA_i = dz1_i W1_i[:, o:o+a]
-    GemmNN g{};
+    NnArgs g{};
     g.dY = e->c_dz1; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W1; g.ldw = e->Lc.ld1; g.p_ns = e->Lc.size; g.k_off = e->o;
     g.dX = e->dA; g.ldx = e->a4; g.dx_ns = (long)B * e->a4; g.M = B; g.Kout = e->a;
     RCCHK(launch_nn(e, s, g, nq));
@@ -344,20 +360,20 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   {
     ActorHeadBwd h{};
     h.dA = e->dA; h.dA_ns = (long)B * e->a4; h.ldA = e->a4; h.nq = nq; h.tg = e->a_tg; h.a4 = e->a4; h.eps = e->eps[sb_a];
-    h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.z2 = e->a_z2; h.st2 = e->a_st2; h.h2 = e->a_h2;
-    h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.rpw = e->rpw; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
+    h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.xh2 = e->a_xh2; h.rstd2 = e->a_rs2; h.h2 = e->a_h2;
+    h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
     h.part = e->part; h.nblk = e->nblk;
     hipLaunchKernelGGL(k_actor_head_bwd, dim3(e->nblk), dim3(256), 0, s, h);
     HIPCHK(hipGetLastError());
   }
   {  // head: dWh = du^T h2, dbh
-    GemmTN g{};
+    TnArgs g{};
     g.dY = e->a_du; g.ldy = e->ldu; g.N = e->nh; g.X = e->a_h2; g.ldx = HID; g.K = HID;
     g.dW = e->Ga + e->La.Wh; g.ldw = HID; g.dbias = e->Ga + e->La.bh; g.M = B;
     RCCHK(launch_tn(e, s, g, 1));
   }
   {
-    GemmTN g{};
+    TnArgs g{};
     g.dY = e->a_dz2; g.ldy = HID; g.N = HID; g.X = e->a_h1; g.ldx = HID; g.K = HID;
     g.dW = e->Ga + e->La.W2; g.ldw = HID; g.dbias = e->Ga + e->La.b2; g.M = B;
     g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
@@ -365,19 +381,19 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     RCCHK(launch_tn(e, s, g, 1));
   }
   {
-    GemmNN g{};
+    NnArgs g{};
     g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, g, 1));
   }
   {
     LnBwd l{};
-    l.dh = e->a_dh1; l.z = e->a_z1; l.st = e->a_st1; l.h = e->a_h1; l.gamma = e->Pa + e->La.g1;
-    l.B = B; l.ln = ln; l.rpw = e->rpw; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.nblk = e->nblk;
+    l.dh = e->a_dh1; l.xh = e->a_xh1; l.h = e->a_h1; l.rstd = e->a_rs1; l.gamma = e->Pa + e->La.g1;
+    l.B = B; l.ln = ln; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.nblk = e->nblk;
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 1), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {
-    GemmTN g{};
+    TnArgs g{};
     g.dY = e->a_dz1; g.ldy = HID; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.K = e->o;
     g.dW = e->Ga + e->La.W1; g.ldw = e->La.ld1; g.dbias = e->Ga + e->La.b1; g.M = B;
     g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
@@ -399,8 +415,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   }
   if (!td3) {
     if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
-      RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, nullptr, nullptr, nullptr, nullptr));
-      ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al, e->rpw);
+      RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, none, nullptr, nullptr));
+      ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
       RCCHK(launch_tail(e, s, t));
     }
     AlphaArgs al{};
@@ -507,7 +523,7 @@ void sactd3_destroy(sactd3_engine* e) {
 static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_ac) {
   const sactd3_config& c = e->cfg;
   if (c.abi_version != SACTD3_ABI_VERSION) return e->fail(SACTD3_EINVAL, "abi_version mismatch");
-  if (c.ob_dim < 1 || c.ac_dim < 1 || c.ac_dim > 64) return e->fail(SACTD3_EINVAL, "ob_dim >= 1 and 1 <= ac_dim <= 64 required");
+  if (c.ob_dim < 1 || c.ac_dim < 1 || c.ac_dim > 32) return e->fail(SACTD3_EINVAL, "ob_dim >= 1 and 1 <= ac_dim <= 32 required");
   if (c.batch_size < 1 || c.rb_capacity < 1 || c.max_envs < 1) return e->fail(SACTD3_EINVAL, "batch_size, rb_capacity, max_envs must be positive");
   if (c.actor_update_delay < 0 || c.crit_targ_update_freq < 1) return e->fail(SACTD3_EINVAL, "actor_update_delay >= 0 and crit_targ_update_freq >= 1 required");
   if (!min_ac || !max_ac) return e->fail(SACTD3_EINVAL, "min_ac / max_ac required");
@@ -529,8 +545,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   e->rec_f = round_up(e->ldc + e->ldo + 2, 16); e->rec4 = e->rec_f / 4;
   e->La = make_layout(e->o, e->nh); e->Lc = make_layout(e->o + e->a, 1);
   e->nq_actor = td3 ? 1 : 2;
-  e->rpw = std::max(1, (e->B + 255) / 256);
-  e->nblk = (e->B + 4 * e->rpw - 1) / (4 * e->rpw);
+  e->nblk = (e->B + 15) / 16;
   e->maxn = c.max_envs;
   e->stage_rows = std::max(c.max_envs, 256);
   const size_t B = e->B, BH = B * HID;
@@ -551,11 +566,11 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->act_scratch, B * e->a4));
   for (int s = 0; s < SACTD3_NUM_SITES; ++s)
     RCCHK(dalloc(e, &e->eps[s], std::max<size_t>(B, e->maxn) * e->a));
-  RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_st1, 2 * B));
-  RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_st2, 2 * B));
+  RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_xh1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_rs1, B));
+  RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_xh2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_rs2, B));
   RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu));
   RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
-  RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_st1, 4 * B));
+  RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_xh1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_rs1, 2 * B));
   RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));
   RCCHK(dalloc(e, &e->t_z1, 2 * BH)); RCCHK(dalloc(e, &e->t_z2, 2 * BH));
   RCCHK(dalloc(e, &e->q, 2 * B)); RCCHK(dalloc(e, &e->qt, 2 * B)); RCCHK(dalloc(e, &e->y, B)); RCCHK(dalloc(e, &e->q_pi, 2 * B));
@@ -892,9 +907,9 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
     memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
   }
   HIPCHK(hipMemcpyAsync(e->p_x, e->h_obs, sizeof(float) * (size_t)n * e->ldo, hipMemcpyHostToDevice, e->stream));
-  RCCHK(enqueue_trunk(e, e->stream, e->p_x, e->ldo, 0, e->o, n, e->Pa, e->La, 0, 1, e->p_z1, e->p_z2, nullptr, nullptr, nullptr, nullptr));
+  RCCHK(enqueue_trunk(e, e->stream, e->p_x, e->ldo, 0, e->o, n, e->Pa, e->La, 0, 1, e->p_z1, e->p_z2, TrunkStore{nullptr, nullptr, nullptr}, nullptr, nullptr));
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
-  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr, 1);
+  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr);
   RCCHK(launch_tail(e, e->stream, t));
   if (explore) {
     hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
@@ -926,16 +941,16 @@ static std::vector<DbgEntry> dbg_table(sactd3_engine* e) {
   return {
       {"X", e->X, B * e->ldc}, {"Xn", e->Xn, B * e->ldc}, {"Xp", e->Xp, B * e->ldc}, {"rew", e->rew, B}, {"done", e->done, B},
       {"logp_next", e->logp_n, B}, {"logp_pi", e->logp_pi, B}, {"logp_alpha", e->logp_al, B},
-      {"a_z1", e->a_z1, BH}, {"a_h1", e->a_h1, BH}, {"a_z2", e->a_z2, BH}, {"a_h2", e->a_h2, BH}, {"a_du", e->a_du, B * e->ldu},
+      {"a_xh1", e->a_xh1, BH}, {"a_h1", e->a_h1, BH}, {"a_z2", e->a_z2, BH}, {"a_h2", e->a_h2, BH}, {"a_du", e->a_du, B * e->ldu},
       {"a_dz2", e->a_dz2, BH}, {"a_dh1", e->a_dh1, BH}, {"a_dz1", e->a_dz1, BH},
-      {"c_z1", e->c_z1, 2 * BH}, {"c_h1", e->c_h1, 2 * BH}, {"c_z2", e->c_z2, 2 * BH}, {"c_dz2", e->c_dz2, 2 * BH},
-      {"c_dh1", e->c_dh1, 2 * BH}, {"c_dz1", e->c_dz1, 2 * BH}, {"t_z1", e->t_z1, 2 * BH}, {"t_z2", e->t_z2, 2 * BH},
+      {"c_xh1", e->c_xh1, 2 * BH}, {"c_h1", e->c_h1, 2 * BH}, {"c_z2", e->c_z2, 2 * BH}, {"c_dz2", e->c_dz2, 2 * BH},
+      {"c_dh1", e->c_dh1, 2 * BH}, {"c_dz1", e->c_dz1, 2 * BH}, {"t_z2", e->t_z2, 2 * BH},
       {"q", e->q, 2 * B}, {"q_target", e->qt, 2 * B}, {"targ_q", e->y, B}, {"q_pi", e->q_pi, 2 * B}, {"dA", e->dA, 2 * B * e->a4},
   };
 }
 const char* sactd3_debug_names(void) {
-  return "X Xn Xp rew done logp_next logp_pi logp_alpha a_z1 a_h1 a_z2 a_h2 a_du a_dz2 a_dh1 a_dz1 c_z1 c_h1 c_z2 c_dz2 c_dh1 c_dz1 "
-         "t_z1 t_z2 q q_target targ_q q_pi dA grad_actor grad_critics";
+  return "X Xn Xp rew done logp_next logp_pi logp_alpha a_xh1 a_h1 a_z2 a_h2 a_du a_dz2 a_dh1 a_dz1 c_xh1 c_h1 c_z2 c_dz2 c_dh1 c_dz1 "
+         "t_z2 q q_target targ_q q_pi dA grad_actor grad_critics";
 }
 int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_t max_floats) {
   if (!e || !name) return SACTD3_EINVAL;
@@ -994,18 +1009,18 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes) {
   if (!e || !usec || batch < 1 || iters < 1) return SACTD3_EINVAL;
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "gather sweep: buffer is empty");
-  float *X = nullptr, *Xn = nullptr, *Xp = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;
+  float *X = nullptr, *Xn = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;
   const size_t rows = batch;
   hipError_t he = hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (he == hipSuccess) he = hipMalloc(p, bytes); };
-  A((void**)&X, rows * e->ldc * 4); A((void**)&Xn, rows * e->ldc * 4); A((void**)&Xp, rows * e->ldc * 4);
+  A((void**)&X, rows * e->ldc * 4); A((void**)&Xn, rows * e->ldc * 4);
   A((void**)&rw, rows * 4); A((void**)&dn, rows * 4); A((void**)&ix, rows * 4);
   int rc = 0;
   if (he != hipSuccess) rc = e->fail(SACTD3_EHIP, "gather sweep: hipMalloc", he);
   if (rc == 0) {
     GatherArgs g{};
     g.ring = (const float4*)e->ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = ix;
-    g.X = (float4*)X; g.Xp = (float4*)Xp; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
+    g.X = (float4*)X; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
     const long threads = (long)batch * e->rec4;
     const dim3 grid((unsigned)((threads + 255) / 256));
     hipEvent_t t0, t1;
@@ -1026,7 +1041,7 @@ int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec
     // 2*B*T + 4*B with T = 4*(2o+a+1)+1 bytes
     if (algo_bytes) *algo_bytes = 2.0 * batch * (4.0 * (2 * e->o + e->a + 1) + 1.0) + 4.0 * batch;
   }
-  hipFree(X); hipFree(Xn); hipFree(Xp); hipFree(rw); hipFree(dn); hipFree(ix);
+  hipFree(X); hipFree(Xn); hipFree(rw); hipFree(dn); hipFree(ix);
   return rc;
 }
 

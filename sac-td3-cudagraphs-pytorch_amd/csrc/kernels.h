@@ -1,17 +1,22 @@
 // Device code of the SAC/TD3 update engine for gfx950 (MI355X, CDNA4).  wave = 64 lanes throughout.
 //
-// Kernel families
-//   k_gather        replay ring -> batch slot (float4 record chunks, Philox index draw fused)
-//   k_gemm_nt/nn/tn fp32 MFMA (v_mfma_f32_16x16x4_f32) GEMMs, one 16x16 output tile per wave, operands
-//                   streamed straight from L2 (everything on this path is L2-resident), with the
-//                   LayerNorm+ReLU of the producing layer fused into the A-operand load (nt) and the
-//                   bias / LN-affine gradient column sums fused into the weight-gradient GEMM (tn)
-//   k_actor_tail    LN+ReLU -> head GEMV -> tanh-Gaussian sample + log-prob (SAC) / tanh policy (TD3)
-//   k_critic_tail   twin target Q -> min/mix -> entropy -> Bellman target -> twin MSE -> dQ -> head bwd -> LN bwd
-//   k_actorq_tail   twin Q(s, pi(s)) -> min -> actor loss -> dQ routing -> head bwd -> LN bwd (dX only)
-//   k_actor_head_bwd  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd -> LN bwd
-//   k_ln_bwd        LN+ReLU backward of a hidden layer (row per wave)
+// The whole path is latency-bound (B <= 4096 rows, 256-wide layers: everything lives in L2 / Infinity Cache), so
+// every kernel is built the same way: issue ALL of its global loads first (one memory round trip), park them in
+// LDS, then compute out of LDS/registers; reductions are DPP (no ds_bpermute); nothing waits on the host.
+//
+//   k_gather          replay ring -> batch slot (float4 record chunks, Philox index draw fused)
+//   k_nt              Y = pro(A) W^T + b on v_mfma_f32_16x16x4_f32: 16-row x 64-col block, operands staged in LDS;
+//                     pro = LayerNorm+ReLU of the producing layer fused into the A tile; optionally the FIRST
+//                     layer of the MLP (x W1^T + b1) is computed in the same kernel (small input widths)
+//   k_nn              dX = dY W                      (same tiling, W strip staged in LDS)
+//   k_tn              dW = dY^T X  (+ bias gradient, + LayerNorm-affine / head gradients from row partials)
+//   k_actor_tail      LN+ReLU -> head (MFMA, K split over the 4 waves) -> tanh-Gaussian sample + log-prob | TD3 policy
+//   k_critic_tail     twin target Q -> min/mix -> entropy -> Bellman target -> twin MSE -> dQ -> head bwd -> LN bwd
+//   k_actorq_tail     twin Q(s, pi(s)) -> min -> actor loss -> dQ routing -> head bwd -> LN bwd
+//   k_actor_head_bwd  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd (MFMA) -> LN bwd
+//   k_ln_bwd          LN+ReLU backward of hidden layer 1
 //   k_adam / k_polyak / k_alpha_step / k_gradnorm   flat optimiser kernels
+// Row kernels: 256 threads = 16 rows x 16 threads; thread (row, sub) owns columns {4*sub + 64*q + e}.
 // Math follows oracle/manual_grads.py (which is checked against autograd) line by line.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,7 +25,10 @@
 
 #define HID 256
 #define LN_EPS 1e-5f
-#define NSLOT 4            // column-partial slots per block: 0 dgamma, 1 dbeta, 2 dWhead (critic), 3 spare
+#define NSLOT 4            // column-partial slots per row block: 0 dgamma, 1 dbeta, 2 dWhead (critic)
+#define AS 260             // LDS row stride (floats) of 256-wide row tiles: 16-byte aligned, odd in float4 units
+#define WS 68              // LDS row stride of 64-wide strips read with ds_read_b32 (WS mod 8 == 4: conflict-free)
+#define YS 20              // LDS row stride of 16-wide tiles read with ds_read_b32
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,10 +52,23 @@ struct NetLayout {   // float offsets inside one net's parameter block (all mult
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
   return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {   // v_readlane takes/returns raw 32-bit words
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 __device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -62,6 +83,15 @@ __device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x
 __device__ __forceinline__ float4 gate4(float4 v, float4 y) {  // v where y > 0 else 0
   return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
 }
+__device__ __forceinline__ float4 zero_beyond(float4 v, int k, int K) {  // element i of v is column k + i; zero columns >= K
+  if (k + 3 >= K) {
+    if (k >= K) v.x = 0.f;
+    if (k + 1 >= K) v.y = 0.f;
+    if (k + 2 >= K) v.z = 0.f;
+    v.w = 0.f;
+  }
+  return v;
+}
 
 // standard normal for element e of (ctr, site): 4 normals per Philox block via two Box-Muller pairs
 __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned ctr, unsigned site, unsigned e) {
@@ -73,44 +103,62 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
   return (k & 1u) ? rad * sinf(th) : rad * cosf(th);
 }
 
-// One row of 256 held as 4 consecutive columns per lane: LayerNorm (+affine) then the pre-ReLU value.
-// ln == 0: y = z, xhat/rstd unused.
-__device__ __forceinline__ void ln_row(float4 z, const float* gamma, const float* beta, int lane, int ln,
-                                       float4& xhat, float4& y, float& mean, float& rstd) {
+// ---- row-owner layout: thread (row = t >> 4, sub = t & 15) holds v[q] = columns 4*sub + 64*q .. +3, q = 0..3
+struct Row16 { float4 v[4]; };
+__device__ __forceinline__ Row16 row_ld(const float* row, int sub) {
+  Row16 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r.v[q] = ld4(row + 4 * sub + 64 * q);
+  return r;
+}
+__device__ __forceinline__ void row_st(float* row, int sub, const Row16& r) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) st4(row + 4 * sub + 64 * q, r.v[q]);
+}
+__device__ __forceinline__ float row_dot(const Row16& a, const Row16& b) {
+  return (dot4(a.v[0], b.v[0]) + dot4(a.v[1], b.v[1])) + (dot4(a.v[2], b.v[2]) + dot4(a.v[3], b.v[3]));
+}
+__device__ __forceinline__ float row_total(const Row16& a) { return (sum4(a.v[0]) + sum4(a.v[1])) + (sum4(a.v[2]) + sum4(a.v[3])); }
+
+// LayerNorm of one row (ln == 0: identity): xhat, pre-ReLU output y, rstd
+__device__ __forceinline__ void ln_fwd(const Row16& z, const Row16& g, const Row16& be, int ln, Row16& xh, Row16& y, float& rstd) {
   if (ln) {
-    mean = wave_sum(sum4(z)) * (1.0f / HID);
-    const float4 d = z - f4(mean);
-    const float var = wave_sum(dot4(d, d)) * (1.0f / HID);
+    const float mean = row16_sum(row_total(z)) * (1.0f / HID);
+    Row16 d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d.v[q] = z.v[q] - f4(mean);
+    const float var = row16_sum(row_dot(d, d)) * (1.0f / HID);
     rstd = 1.0f / sqrtf(var + LN_EPS);
-    xhat = d * rstd;
-    y = xhat * ld4(gamma + 4 * lane) + ld4(beta + 4 * lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xh.v[q] = d.v[q] * rstd; y.v[q] = xh.v[q] * g.v[q] + be.v[q]; }
   } else {
-    mean = 0.f; rstd = 1.f; xhat = z; y = z;
+    rstd = 1.f; xh = z; y = z;
   }
 }
-
-// LN backward for one row given dy (grad at the LN output, ReLU gate already applied)
-__device__ __forceinline__ float4 ln_row_bwd(float4 dy, float4 xhat, float rstd, const float* gamma, int lane, int ln) {
+// LayerNorm backward of one row: dy = gradient at the LN output with the ReLU gate applied
+__device__ __forceinline__ Row16 ln_bwd(const Row16& dy, const Row16& xh, float rstd, const Row16& g, int ln) {
   if (!ln) return dy;
-  const float4 dxh = dy * ld4(gamma + 4 * lane);
-  const float m1 = wave_sum(sum4(dxh)) * (1.0f / HID);
-  const float m2 = wave_sum(dot4(dxh, xhat)) * (1.0f / HID);
-  return (dxh - f4(m1) - xhat * m2) * rstd;
+  Row16 dxh, dz;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dxh.v[q] = dy.v[q] * g.v[q];
+  const float m1 = row16_sum(row_total(dxh)) * (1.0f / HID);
+  const float m2 = row16_sum(row_dot(dxh, xh)) * (1.0f / HID);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dz.v[q] = (dxh.v[q] - f4(m1) - xh.v[q] * m2) * rstd;
+  return dz;
 }
-
-// Combine the 4 waves' per-lane float4 column accumulators of a block and store one partial row per slot.
-// red: __shared__ float[4 waves][nslots][HID].  Every thread must call this (it contains barriers).
-__device__ __forceinline__ void block_store_partials(float* red, const float4* acc, int nslots, float* dst /*[NSLOT][HID] of this block*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int s = 0; s < nslots; ++s) st4(red + (wave * NSLOT + s) * HID + 4 * lane, acc[s]);
+// Column sums over the 16 rows of a block for `nslots` quantities; cs = __shared__ float[nslots][16][HID].
+// Thread t ends up writing column t of every slot to dst[slot][t].  Contains barriers: all 256 threads call it.
+__device__ __forceinline__ void block_colsum(float* cs, const Row16* vals, int nslots, int row, int sub, float* dst) {
+  for (int s = 0; s < nslots; ++s) row_st(cs + (s * 16 + row) * HID, sub, vals[s]);
   __syncthreads();
-  const int t = threadIdx.x;  // 256 threads = 256 columns
+  const int t = threadIdx.x;
   for (int s = 0; s < nslots; ++s) {
-    const float v = ((red[(0 * NSLOT + s) * HID + t] + red[(1 * NSLOT + s) * HID + t]) +
-                     (red[(2 * NSLOT + s) * HID + t] + red[(3 * NSLOT + s) * HID + t]));
-    dst[s * HID + t] = v;
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += cs[(s * 16 + r) * HID + t];
+    dst[s * HID + t] = a;
   }
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ replay
@@ -118,7 +166,7 @@ struct GatherArgs {
   const float4* ring; int rec4;           // record = rec4 float4 chunks: [s|a : cx][s' : cn][r,d,0,0][pad]
   int cx, cn;                             // chunks of the [s|a] field and of the s' field
   const DevCtl* ctl; int* idx;
-  float4* X; float4* Xp; float4* Xn;      // row stride = cx chunks
+  float4* X; float4* Xn;                  // row stride = cx chunks
   float* rew; float* done;
   int B; int len_override;                // len_override >= 0: use it instead of ctl->rb_len (staged batches)
 };
@@ -139,7 +187,6 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs p) {
   const float4 v = p.ring[(long)id * p.rec4 + c];
   if (c < p.cx) {
     p.X[(long)b * p.cx + c] = v;
-    p.Xp[(long)b * p.cx + c] = v;
   } else if (c < p.cx + p.cn) {
     p.Xn[(long)b * p.cx + (c - p.cx)] = v;
   } else {
@@ -188,310 +235,461 @@ __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
 
 // ------------------------------------------------------------------------------------------------ GEMMs
 // Operand maps of v_mfma_f32_16x16x4_f32 (lane l): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
-// D: col j = l&15, row i = 4*(l>>4) + reg.  The k slot of a lane is free to name ANY k as long as A and B
-// agree, so lane-group kq takes 4 CONSECUTIVE k's (one float4 load) and feeds them to 4 successive MFMAs.
+// D: col j = l&15, row i = 4*(l>>4) + reg.  The k slot of a lane may name ANY k as long as A and B agree, so
+// lane-group kq takes 4 CONSECUTIVE k's (one 16-byte read) and feeds them to 4 successive MFMAs.
 #define MFMA4(acc, a, b)                                                   \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).x, (b).x, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).y, (b).y, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).z, (b).z, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).w, (b).w, acc, 0, 0, 0);
 
-struct GemmNT {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias
-  const float* A; int lda; long a_ns;
-  const float* Wt; int ldw;             // W = Wt + net * p_ns
-  const float* bias;                    // may be null
-  const float* gamma; const float* beta;// LN affine applied to A (PRO == 1)
-  long p_ns;                            // net stride of every parameter pointer
+struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = 16 rows x 64 cols
+  const float* A; int lda; long a_ns;       // !FUSE1: input rows
+  const float* Wt; int ldw; const float* bias; long p_ns;   // W = Wt + net*p_ns, [N][ldw]
+  const float* gamma; const float* beta;    // LN affine applied to the A rows (PRO == 1)
   float* Y; int ldy; long y_ns;
-  float* Hout; long h_ns;               // PRO != 0, optional: store pro(A) rows (tile_n == 0 waves)
-  float* stats; long st_ns;             // PRO == 1, optional: (mean, rstd) per row
-  int M, N, K;
-  int* tick0; int* tick1;               // optional counters bumped by (block 0, thread 0, net 0)
+  int M, N, K;                              // PRO != 0 or FUSE1: K == 256
+  // FUSE1: A rows = x W1^T + b1 computed here (x: [M][ldx], K1 <= 64)
+  const float* X; int ldx; long x_ns; int K1; const float* W1; int ldw1; const float* b1;
+  // optional stores of the prologue's rows by the column-strip-0 blocks (all [M][256] / [M], net stride act_ns / M)
+  float* xh_out; float* h_out; float* rstd_out; long act_ns;
+  int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
 };
 
-// PRO: 0 none (any K), 1 LayerNorm+ReLU (K == 256), 2 ReLU (K == 256)
-template <int PRO>
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmNT p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, net = blockIdx.z;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && net == 0) {
+// PRO: 0 none, 1 LayerNorm+ReLU, 2 ReLU.  FUSE1: the A rows are produced by a fused first layer.
+template <int PRO, bool FUSE1>
+__global__ __launch_bounds__(256) void k_nt(NtArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[16 * AS];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * AS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
+  const int r = lane & 15, kq = lane >> 4;
+  if (blockIdx.x == 0 && t == 0 && net == 0) {
     if (p.tick0) *p.tick0 += 1;
     if (p.tick1) *p.tick1 += 1;
   }
-  const int tiles_n = (p.N + 15) >> 4, tiles_m = (p.M + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_n) return;
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int r = lane & 15, kq = lane >> 4;
-  const int m = min(tm * 16 + r, p.M - 1), n = min(tn * 16 + r, p.N - 1);
-  const float* Arow = p.A + net * p.a_ns + (long)m * p.lda;
-  const float* Wrow = p.Wt + net * p.p_ns + (long)n * p.ldw;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (PRO == 0) {
-#pragma unroll 4
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
-      const int k = k0 + 4 * kq;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a;
-      if (k < p.K) {   // lda, ldw >= round4(K): the float4 is in-bounds; zero what lies beyond K
-        a = ld4(Arow + k); w = ld4(Wrow + k);
-        if (k + 3 >= p.K) {
-          if (k + 1 >= p.K) { a.y = 0.f; w.y = 0.f; }
-          if (k + 2 >= p.K) { a.z = 0.f; w.z = 0.f; }
-          a.w = 0.f; w.w = 0.f;
+  const int strips = (p.N + 63) >> 6;
+  const int tm = blockIdx.x / strips, strip = blockIdx.x % strips;
+  const int m0 = tm * 16, n0 = strip * 64;
+  const float* Wn = p.Wt + net * p.p_ns;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < p.K; k0 += 256) {     // one pass unless an unfused first layer is wider than 256
+    int kc = 16;                                 // chunk width: power of two in [16, 256] (zero-filled beyond K)
+    while (kc < 256 && kc < p.K - k0) kc <<= 1;
+    const int kc4 = kc >> 2, ksh = 31 - __clz(kc4);
+    if (k0) __syncthreads();
+    // ---- 1. every global load of this pass, issued back to back
+    float4 vw[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = t + 256 * u;
+      const int row = i >> ksh, c4 = i & (kc4 - 1), k = k0 + 4 * c4, n = n0 + row;
+      vw[u] = f4(0.f);
+      if (row < 64 && n < p.N && k < p.K) vw[u] = zero_beyond(ld4(Wn + (long)n * p.ldw + k), k, p.K);
+    }
+    float4 va[4];
+    Row16 g, be;
+    if (PRO == 1) {
+      g = row_ld(p.gamma + net * p.p_ns, t & 15); be = row_ld(p.beta + net * p.p_ns, t & 15);
+    }
+    if (!FUSE1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = t + 256 * u;
+        const int row = i >> ksh, c4 = i & (kc4 - 1), k = k0 + 4 * c4, m = m0 + row;
+        va[u] = f4(0.f);
+        if (row < 16 && m < p.M && k < p.K) va[u] = zero_beyond(ld4(p.A + net * p.a_ns + (long)m * p.lda + k), k, p.K);
+      }
+    } else {
+      // first layer, transposed product so that a lane ends up with 4 consecutive columns of one row:
+      // D[i = n][j = m] = sum_k W1[n][k] x[m][k]; wave w owns column tiles w, w+4, w+8, w+12
+      const int C1 = (p.K1 + 15) >> 4;      // <= 4
+      const int mx = min(m0 + r, p.M - 1);
+      float4 xv[4], wv[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 16 * c + 4 * kq;
+        xv[c] = f4(0.f);
+        if (c < C1 && k < p.K1) xv[c] = zero_beyond(ld4(p.X + net * p.x_ns + (long)mx * p.ldx + k), k, p.K1);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          wv[tt][c] = f4(0.f);
+          if (c < C1 && k < p.K1)
+            wv[tt][c] = zero_beyond(ld4(p.W1 + net * p.p_ns + (long)((wave + 4 * tt) * 16 + r) * p.ldw1 + k), k, p.K1);
         }
       }
-      MFMA4(acc, a, w);
-    }
-  } else {
-    float4 av[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) av[c] = ld4(Arow + c * 16 + 4 * kq);
-    float mean = 0.f, rstd = 1.f;
-    if (PRO == 1) {
-      float s = 0.f;
+      for (int tt = 0; tt < 4; ++tt) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 16; ++c) s += sum4(av[c]);
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-      mean = s * (1.0f / HID);
-      float q = 0.f;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) { const float4 d = av[c] - f4(mean); q += dot4(d, d); }
-      q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-      rstd = 1.0f / sqrtf(q * (1.0f / HID) + LN_EPS);
-      const float* g = p.gamma + net * p.p_ns; const float* be = p.beta + net * p.p_ns;
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-        av[c] = relu4((av[c] - f4(mean)) * rstd * ld4(g + c * 16 + 4 * kq) + ld4(be + c * 16 + 4 * kq));
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) av[c] = relu4(av[c]);
-    }
-    if (tn == 0 && tm * 16 + r < p.M) {
-      if (p.Hout) {
-        float* h = p.Hout + net * p.h_ns + (long)m * HID;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) st4(h + c * 16 + 4 * kq, av[c]);
-      }
-      if (PRO == 1 && p.stats && kq == 0) {
-        float* st = p.stats + net * p.st_ns + 2 * (long)m;
-        st[0] = mean; st[1] = rstd;
+        for (int c = 0; c < 4; ++c)
+          if (c < C1) { MFMA4(z, wv[tt][c], xv[c]); }
+        const int col = (wave + 4 * tt) * 16 + 4 * kq;      // lane (m = r, kq): z[reg] = z1[m][col + reg]
+        const float4 b1 = ld4(p.b1 + net * p.p_ns + col);
+        st4(As + r * AS + col, make_float4(z[0] + b1.x, z[1] + b1.y, z[2] + b1.z, z[3] + b1.w));
       }
     }
+    // ---- 2. park in LDS
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float4 w = ld4(Wrow + c * 16 + 4 * kq);
-      MFMA4(acc, av[c], w);
+    for (int u = 0; u < 16; ++u) {
+      const int i = t + 256 * u;
+      const int row = i >> ksh, c4 = i & (kc4 - 1);
+      if (row < 64) st4(Ws + row * AS + 4 * c4, vw[u]);
+    }
+    if (!FUSE1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = t + 256 * u;
+        const int row = i >> ksh, c4 = i & (kc4 - 1);
+        if (row < 16) st4(As + row * AS + 4 * c4, va[u]);
+      }
+    }
+    __syncthreads();
+    // ---- 3. prologue on the A rows (16 threads per row)
+    if (PRO != 0) {
+      const int row = t >> 4, sub = t & 15;
+      const Row16 z = row_ld(As + row * AS, sub);
+      Row16 xh, y;
+      float rstd = 1.f;
+      if (PRO == 1) ln_fwd(z, g, be, 1, xh, y, rstd); else { xh = z; y = z; }
+      Row16 h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+      row_st(As + row * AS, sub, h);
+      const int m = m0 + row;
+      if (strip == 0 && m < p.M) {
+        if (p.xh_out) row_st(p.xh_out + net * p.act_ns + (long)m * HID, sub, xh);
+        if (p.h_out) row_st(p.h_out + net * p.act_ns + (long)m * HID, sub, h);
+        if (p.rstd_out && sub == 0) p.rstd_out[(long)net * p.M + m] = rstd;
+      }
+      __syncthreads();
+    }
+    // ---- 4. MFMA: wave w -> output columns n0 + 16 w .. +15
+    const int chunks = kc >> 4;
+    const float* arow = As + r * AS + 4 * kq;
+    const float* wrow = Ws + (wave * 16 + r) * AS + 4 * kq;
+#pragma unroll 4
+    for (int c = 0; c < chunks; c += 2) {
+      const float4 a0 = ld4(arow + 16 * c), w0 = ld4(wrow + 16 * c);
+      MFMA4(acc0, a0, w0);
+      if (c + 1 < chunks) {
+        const float4 a1 = ld4(arow + 16 * c + 16), w1 = ld4(wrow + 16 * c + 16);
+        MFMA4(acc1, a1, w1);
+      }
     }
   }
-  const int col = tn * 16 + (lane & 15);
+  const int col = n0 + wave * 16 + (lane & 15);
   if (col < p.N) {
     const float bv = p.bias ? p.bias[net * p.p_ns + col] : 0.f;
     float* y = p.Y + net * p.y_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = tm * 16 + 4 * (lane >> 4) + i;
-      if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bv;
+      const int row = m0 + 4 * (lane >> 4) + i;
+      if (row < p.M) y[(long)row * p.ldy + col] = (acc0[i] + acc1[i]) + bv;
     }
   }
 }
 
-struct GemmNN {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout]
-  const float* dY; long dy_ns;          // row stride HID
+struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout] ; block = 16 rows x 64 cols
+  const float* dY; long dy_ns;              // row stride HID
   const float* Wt; int ldw; long p_ns; int k_off;
   float* dX; int ldx; long dx_ns;
   int M, Kout;
 };
 
-__global__ __launch_bounds__(256) void k_gemm_nn(GemmNN p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, net = blockIdx.z;
-  const int tiles_k = (p.Kout + 15) >> 4, tiles_m = (p.M + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_k) return;
-  const int tm = tile / tiles_k, tk = tile % tiles_k;
+__global__ __launch_bounds__(256) void k_nn(NnArgs p) {
+  __shared__ __attribute__((aligned(16))) float Ds[16 * AS];
+  __shared__ __attribute__((aligned(16))) float Wn[HID * WS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  const int m = min(tm * 16 + r, p.M - 1);
-  const int kc = p.k_off + min(tk * 16 + r, p.Kout - 1);
-  const float* Drow = p.dY + net * p.dy_ns + (long)m * HID;
-  const float* Wc = p.Wt + net * p.p_ns + kc;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int c = 0; c < HID / 16; ++c) {
-    const int n = c * 16 + 4 * kq;
-    const float4 a = ld4(Drow + n);
-    float4 b;
-    b.x = Wc[(long)(n + 0) * p.ldw]; b.y = Wc[(long)(n + 1) * p.ldw];
-    b.z = Wc[(long)(n + 2) * p.ldw]; b.w = Wc[(long)(n + 3) * p.ldw];
-    MFMA4(acc, a, b);
+  const int strips = (p.Kout + 63) >> 6;
+  const int tm = blockIdx.x / strips, strip = blockIdx.x % strips;
+  const int m0 = tm * 16, c0 = strip * 64;          // c0: first output column of this block
+  const float* W = p.Wt + net * p.p_ns + p.k_off;
+  float4 va[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = t + 256 * u, row = i >> 6, c4 = i & 63, m = m0 + row;
+    va[u] = m < p.M ? ld4(p.dY + net * p.dy_ns + (long)m * HID + 4 * c4) : f4(0.f);
   }
-  const int col = tk * 16 + (lane & 15);
+  if (((p.k_off | p.ldw) & 3) == 0) {           // 16-byte aligned strip: 16 float4 per thread
+    float4 vw[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = t + 256 * u, n = i >> 4, c4 = i & 15, col = c0 + 4 * c4;
+      vw[u] = col < p.Kout ? zero_beyond(ld4(W + (long)n * p.ldw + col), col, p.Kout) : f4(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = t + 256 * u, n = i >> 4, c4 = i & 15;
+      st4(Wn + n * WS + 4 * c4, vw[u]);
+    }
+  } else {                                      // narrow unaligned slice (dQ/da: columns o .. o+a of W1)
+    for (int i = t; i < HID * 64; i += 256) {
+      const int n = i >> 6, cc = i & 63, col = c0 + cc;
+      Wn[n * WS + cc] = col < p.Kout ? W[(long)n * p.ldw + col] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = t + 256 * u, row = i >> 6, c4 = i & 63;
+    st4(Ds + row * AS + 4 * c4, va[u]);
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* arow = Ds + r * AS + 4 * kq;
+  const float* wcol = Wn + (4 * kq) * WS + wave * 16 + r;
+#pragma unroll 4
+  for (int c = 0; c < 16; c += 2) {
+    const float4 a0 = ld4(arow + 16 * c), a1 = ld4(arow + 16 * c + 16);
+    const float* w0 = wcol + (16 * c) * WS; const float* w1 = w0 + 16 * WS;
+    const float4 b0 = make_float4(w0[0], w0[WS], w0[2 * WS], w0[3 * WS]);
+    const float4 b1 = make_float4(w1[0], w1[WS], w1[2 * WS], w1[3 * WS]);
+    MFMA4(acc0, a0, b0);
+    MFMA4(acc1, a1, b1);
+  }
+  const int col = c0 + wave * 16 + (lane & 15);
   if (col < p.Kout) {
     float* x = p.dX + net * p.dx_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = tm * 16 + 4 * (lane >> 4) + i;
-      if (row < p.M) x[(long)row * p.ldx + col] = acc[i];
+      const int row = m0 + 4 * (lane >> 4) + i;
+      if (row < p.M) x[(long)row * p.ldx + col] = acc0[i] + acc1[i];
     }
   }
 }
 
-struct GemmTN {              // dW[N, ldw] = dY[M,N]^T * X[M,K]   (columns K..ldw-1 written as 0)
+struct TnArgs {              // dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 written as 0); block = 16 rows(n) x 64 cols(k)
   const float* dY; int ldy; long dy_ns; int N;
   const float* X; int ldx; long x_ns; int K;
   float* dW; int ldw;
   float* dbias;                          // optional: dbias[n] = sum_m dY[m][n]
   long g_ns;                             // net stride of every gradient pointer
   int M;
-  // column partials produced by a row kernel: part[net][blk][NSLOT][HID] -> fin_dst[e][n] = sum_blk part[..][fin_slot[e]][n]
+  // column partials from a row kernel: part[net][blk][NSLOT][HID] -> fin_dst[e][n] = sum_blk part[..][fin_slot[e]][n]
   const float* part; int nblk; int nfin; int fin_slot[3]; float* fin_dst[3];
   const float* part_s; float* fin_s;     // optional scalar: fin_s[0] = sum_blk part_s[net][blk][0]
 };
 
-__global__ __launch_bounds__(256) void k_gemm_tn(GemmTN p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, net = blockIdx.z;
-  const int tiles_k = (p.ldw + 15) >> 4, tiles_n = (p.N + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_n * tiles_k) return;
-  const int tn = tile / tiles_k, tk = tile % tiles_k;
+__global__ __launch_bounds__(256) void k_tn(TnArgs p) {
+  __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
+  __shared__ __attribute__((aligned(16))) float Xs[256 * WS];
+  __shared__ float red[16 * 17];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  const int nA = min(tn * 16 + r, p.N - 1);
-  const int kB = tk * 16 + r;
-  const bool kval = kB < p.K;
-  const float* Dc = p.dY + net * p.dy_ns + nA;
-  const float* Xc = p.X + net * p.x_ns + min(kB, p.K - 1);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float asum = 0.f;
-  const int chunks = (p.M + 15) >> 4;
-#pragma unroll 2
-  for (int c = 0; c < chunks; ++c) {
-    float4 a, b;
-    float* ap = &a.x; float* bp = &b.x;
+  const int strips = (p.ldw + 63) >> 6;
+  const int tn = blockIdx.x / strips, strip = blockIdx.x % strips;
+  const int n0 = tn * 16, c0 = strip * 64;
+  const float* dY = p.dY + net * p.dy_ns;
+  const float* X = p.X + net * p.x_ns;
+  const int Kr = (p.K + 3) & ~3;          // rows of X hold at least round4(K) floats
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
+  for (int mb = 0; mb < p.M; mb += 256) {
+    if (mb) __syncthreads();
+    float4 vy[4], vx[16];
+    const bool yal = ((p.ldy & 3) == 0) && n0 + 16 <= ((p.N + 3) & ~3);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int mm = c * 16 + 4 * kq + j;
-      const bool v = mm < p.M;
-      const int mc = v ? mm : p.M - 1;
-      const float av = Dc[(long)mc * p.ldy], bv = Xc[(long)mc * p.ldx];
-      ap[j] = v ? av : 0.f;
-      bp[j] = (v && kval) ? bv : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4;
+      vy[u] = f4(0.f);
+      if (m < p.M) {
+        const float* src = dY + (long)m * p.ldy + n;
+        if (yal) vy[u] = zero_beyond(ld4(src), n, p.N);
+        else { if (n < p.N) vy[u].x = src[0]; if (n + 1 < p.N) vy[u].y = src[1]; if (n + 2 < p.N) vy[u].z = src[2]; if (n + 3 < p.N) vy[u].w = src[3]; }
+      }
     }
-    asum += (a.x + a.y) + (a.z + a.w);
-    MFMA4(acc, a, b);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = t + 256 * u, row = i >> 4, c4 = i & 15, m = mb + row, k = c0 + 4 * c4;
+      vx[u] = (m < p.M && k < Kr) ? zero_beyond(ld4(X + (long)m * p.ldx + k), k, p.K) : f4(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = t + 256 * u; st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int i = t + 256 * u; st4(Xs + (i >> 4) * WS + 4 * (i & 15), vx[u]); }
+    __syncthreads();
+    const float* ycol = Ys + (4 * kq) * YS + r;
+    const float* xcol = Xs + (4 * kq) * WS + wave * 16 + r;
+#pragma unroll 4
+    for (int c = 0; c < 16; c += 2) {
+      const float* y0 = ycol + (16 * c) * YS; const float* y1 = y0 + 16 * YS;
+      const float* x0 = xcol + (16 * c) * WS; const float* x1 = x0 + 16 * WS;
+      const float4 a0 = make_float4(y0[0], y0[YS], y0[2 * YS], y0[3 * YS]);
+      const float4 b0 = make_float4(x0[0], x0[WS], x0[2 * WS], x0[3 * WS]);
+      const float4 a1 = make_float4(y1[0], y1[YS], y1[2 * YS], y1[3 * YS]);
+      const float4 b1 = make_float4(x1[0], x1[WS], x1[2 * WS], x1[3 * WS]);
+      MFMA4(acc0, a0, b0);
+      MFMA4(acc1, a1, b1);
+    }
+    if (strip == 0 && p.dbias) {
+      const int col = t & 15, part = t >> 4;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bsum += Ys[(part * 16 + i) * YS + col];
+    }
   }
-  if (tk == 0) {
-    const int n = tn * 16 + r;
+  if (strip == 0) {
+    const int col = t & 15, part = t >> 4, n = n0 + col;
     if (p.dbias) {
-      float s = asum;
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-      if (kq == 0 && n < p.N) p.dbias[net * p.g_ns + n] = s;
+      red[part * 17 + col] = bsum;
+      __syncthreads();
+      if (t < 16 && n < p.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i * 17 + t];
+        p.dbias[net * p.g_ns + n] = s;
+      }
     }
-    for (int e = 0; e < p.nfin; ++e) {
+    for (int e = 0; e < p.nfin; ++e) {       // 16 threads per column, blocks strided over them, all loads independent
       float s = 0.f;
       if (n < p.N)
-        for (int blk = kq; blk < p.nblk; blk += 4)
+        for (int blk = part; blk < p.nblk; blk += 16)
           s += p.part[(((long)net * p.nblk + blk) * NSLOT + p.fin_slot[e]) * HID + n];
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-      if (kq == 0 && n < p.N) p.fin_dst[e][net * p.g_ns + n] = s;
+      __syncthreads();
+      red[part * 17 + col] = s;
+      __syncthreads();
+      if (t < 16 && n < p.N) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i * 17 + t];
+        p.fin_dst[e][net * p.g_ns + n] = a;
+      }
     }
-    if (p.fin_s && tn == 0) {
+    if (p.fin_s && tn == 0 && wave == 0) {
       float s = 0.f;
       for (int blk = lane; blk < p.nblk; blk += 64) s += p.part_s[((long)net * p.nblk + blk) * 2];
       s = wave_sum(s);
       if (lane == 0) p.fin_s[net * p.g_ns] = s;
     }
   }
-  const int col = tk * 16 + (lane & 15);
+  const int col = c0 + wave * 16 + (lane & 15);
   if (col < p.ldw) {
     float* w = p.dW + net * p.g_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = tn * 16 + 4 * (lane >> 4) + i;
-      if (row < p.N) w[(long)row * p.ldw + col] = (col < p.K) ? acc[i] : 0.f;
+      const int row = n0 + 4 * (lane >> 4) + i;
+      if (row < p.N) w[(long)row * p.ldw + col] = (col < p.K) ? acc0[i] + acc1[i] : 0.f;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ row kernels
-// Layout of every row kernel: 256 threads = 4 waves, one row of 256 per wave at a time (lane holds columns
-// 4*lane .. 4*lane+3), `rpw` rows per wave.  Row index = (block * 4 + wave) * rpw + it.
-
 struct ActorTail {
   const float* z2;                       // [B][HID] pre-LN output of hidden layer 2
   const float* P; NetLayout L;           // actor parameter block (online or target)
-  int B, o, a, ln, sac, mode, train, rpw;
+  int B, o, a, ln, sac, mode, train;
   // mode: SAC 0 = sample, 1 = mode (tanh(mean));  TD3 0 = policy, 1 = target smoothing, 2 = explore
   const DevCtl* ctl; const int* ctr; int site_buf; unsigned site_code;
   float* eps;                            // [B][a] draws used (written in native mode, read when injected)
   const float* scale; const float* bias; const float* min_ac; const float* max_ac;
   float* dst; int ldd; int dst_off;      // action -> dst[b * ldd + dst_off + j]
+  const float* obs_src; int lds;         // optional: dst[b][0:o] = obs_src[b][0:o] first (builds [s | pi(s)] rows)
   float* logp;                           // [B] (SAC)
-  float* h2; float* st2; float* tg;      // train stores: h2 [B][HID], st2 [B][2], tg [B][4][a4] (t, std, y, -)
+  float* h2; float* xh2; float* rstd2; float* tg;   // train stores: h2, xhat2 [B][HID], rstd2 [B], tg [B][4][a4] (t, std, y)
   int a4;
   float td3_std, td3_c, noise_std;
 };
 
 __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* g2 = p.P + p.L.g2; const float* be2 = p.P + p.L.be2;
-  const float* Wh = p.P + p.L.Wh; const float* bh = p.P + p.L.bh;
-  const int nh = p.L.nh;
-  for (int it = 0; it < p.rpw; ++it) {
-    const int b = (blockIdx.x * 4 + wave) * p.rpw + it;
-    if (b >= p.B) break;
-    float4 xhat, y; float mean, rstd;
-    ln_row(ld4(p.z2 + (long)b * HID + 4 * lane), g2, be2, lane, p.ln, xhat, y, mean, rstd);
-    const float4 h = relu4(y);
+  __shared__ __attribute__((aligned(16))) float Hs[16 * AS];
+  __shared__ float Up[4 * 16 * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row = t >> 4, sub = t & 15, r = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
+  const int nh = p.L.nh, T = (nh + 15) >> 4;     // head column tiles (<= 4)
+  const float* Wh = p.P + p.L.Wh;
+  // loads first: my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3)
+  const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
+  Row16 g, be;
+  if (p.ln) { g = row_ld(p.P + p.L.g2, sub); be = row_ld(p.P + p.L.be2, sub); }
+  float4 wf[4][4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int n = tt * 16 + r;
+      wf[tt][ci] = (tt < T && n < nh) ? ld4(Wh + (long)n * HID + (4 * wave + ci) * 16 + 4 * kq) : f4(0.f);
+    }
+  Row16 xh, y; float rstd;
+  ln_fwd(z, g, be, p.ln, xh, y, rstd);
+  Row16 h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  row_st(Hs + row * AS, sub, h);
+  if (valid) {
     if (p.train) {
-      st4(p.h2 + (long)b * HID + 4 * lane, h);
-      if (lane == 0) { p.st2[2 * b] = mean; p.st2[2 * b + 1] = rstd; }
+      row_st(p.h2 + (long)b * HID, sub, h);
+      row_st(p.xh2 + (long)b * HID, sub, xh);
+      if (sub == 0) p.rstd2[b] = rstd;
     }
-    // head GEMV: output j lands in lane (j mod a) as u0 (j < a) or u1 (j >= a)
-    float u0 = 0.f, u1 = 0.f;
-    for (int j = 0; j < nh; ++j) {
-      const float s = wave_sum(dot4(h, ld4(Wh + (long)j * HID + 4 * lane))) + bh[j];
-      if (j < p.a) { if (lane == j) u0 = s; } else { if (lane == j - p.a) u1 = s; }
+    if (p.obs_src)
+      for (int k = sub; k < p.o; k += 16) p.dst[(long)b * p.ldd + k] = p.obs_src[(long)b * p.lds + k];
+  }
+  __syncthreads();
+  // head: u[16][nh] = h[16][256] Wh^T, K split over the 4 waves
+  {
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float4 av = ld4(Hs + r * AS + (4 * wave + ci) * 16 + 4 * kq);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        if (tt < T) { MFMA4(acc[tt], av, wf[tt][ci]); }
     }
-    float lp = 0.f;
-    if (lane < p.a) {
-      const int j = lane;
-      float e = 0.f;
-      const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
-      if (need_eps) {
-        if (p.ctl->inject_eps[p.site_buf]) e = p.eps[(long)b * p.a + j];
-        else { e = philox_normal(p.ctl->seed, (unsigned)*p.ctr, p.site_code, (unsigned)(b * p.a + j)); p.eps[(long)b * p.a + j] = e; }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+      if (tt < T)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Up[(wave * 16 + 4 * kq + i) * 64 + tt * 16 + r] = acc[tt][i];
+  }
+  __syncthreads();
+  float lp = 0.f;
+  for (int j = sub; j < p.a; j += 16) {
+    const float* u = Up + row * 64;
+    const float u0 = ((u[j] + u[1024 + j]) + (u[2048 + j] + u[3072 + j])) + p.P[p.L.bh + j];
+    float e = 0.f;
+    const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
+    if (need_eps) {
+      if (p.ctl->inject_eps[p.site_buf]) e = p.eps[(long)bc * p.a + j];
+      else { e = philox_normal(p.ctl->seed, (unsigned)*p.ctr, p.site_code, (unsigned)(bc * p.a + j)); if (valid) p.eps[(long)b * p.a + j] = e; }
+    }
+    const float sc = p.scale[j], bi = p.bias[j];
+    float act;
+    if (p.sac) {
+      const int j1 = p.a + j;
+      const float u1 = ((u[j1] + u[1024 + j1]) + (u[2048 + j1] + u[3072 + j1])) + p.P[p.L.bh + j1];
+      const float tt = tanhf(u1);
+      const float log_std = -5.0f + 3.5f * (tt + 1.0f);
+      const float sd = expf(log_std);
+      const float x = u0 + e * sd;
+      const float yt = tanhf(x);
+      act = yt * sc + bi;
+      const float dx = x - u0;
+      float l = -(dx * dx) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;
+      l -= logf(sc * (1.0f - yt * yt) + 1e-6f);
+      lp += l;
+      if (p.mode == 1) act = tanhf(u0) * sc + bi;
+      if (p.train && valid) {
+        float* tg = p.tg + (long)b * 4 * p.a4;
+        tg[j] = tt; tg[p.a4 + j] = sd; tg[2 * p.a4 + j] = yt;
       }
-      const float sc = p.scale[j], bi = p.bias[j];
-      float act;
-      if (p.sac) {
-        const float t = tanhf(u1);
-        const float log_std = -5.0f + 3.5f * (t + 1.0f);
-        const float sd = expf(log_std);
-        const float x = u0 + e * sd;
-        const float yt = tanhf(x);
-        act = yt * sc + bi;
-        const float dx = x - u0;
-        lp = -(dx * dx) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;
-        lp -= logf(sc * (1.0f - yt * yt) + 1e-6f);
-        if (p.mode == 1) act = tanhf(u0) * sc + bi;
-        if (p.train) {
-          float* tg = p.tg + (long)b * 4 * p.a4;
-          tg[j] = t; tg[p.a4 + j] = sd; tg[2 * p.a4 + j] = yt;
-        }
-      } else {
-        const float th = tanhf(u0);
-        act = th * sc + bi;
-        if (p.mode == 1) {
-          const float nz = fminf(fmaxf(e * p.td3_std, -p.td3_c), p.td3_c);
-          act = fminf(fmaxf(act + nz, p.min_ac[j]), p.max_ac[j]);
-        } else if (p.mode == 2) {
-          act = act + e * (sc * p.noise_std);
-        }
-        if (p.train) p.tg[(long)b * 4 * p.a4 + j] = th;
+    } else {
+      const float th = tanhf(u0);
+      act = th * sc + bi;
+      if (p.mode == 1) {
+        const float nz = fminf(fmaxf(e * p.td3_std, -p.td3_c), p.td3_c);
+        act = fminf(fmaxf(act + nz, p.min_ac[j]), p.max_ac[j]);
+      } else if (p.mode == 2) {
+        act = act + e * (sc * p.noise_std);
       }
-      p.dst[(long)b * p.ldd + p.dst_off + j] = act;
+      if (p.train && valid) p.tg[(long)b * 4 * p.a4 + j] = th;
     }
-    if (p.sac && p.logp) {
-      const float s = wave_sum(lp);
-      if (lane == 0) p.logp[b] = s;
-    }
+    if (valid) p.dst[(long)b * p.ldd + p.dst_off + j] = act;
+  }
+  if (p.sac && p.logp) {
+    lp = row16_sum(lp);
+    if (sub == 0 && valid) p.logp[b] = lp;
   }
 }
 
@@ -499,193 +697,260 @@ struct CriticTail {
   const float* z2t; const float* z2;     // [2][B][HID] target / online pre-LN layer-2 outputs
   const float* PT; const float* P; long p_ns; NetLayout L;
   const float* rew; const float* done; const float* logp_next; const float* log_alpha;
-  int B, ln, sac, bcq, rpw; float gamma;
+  int B, ln, sac, bcq; float gamma;
   float* qt; float* y; float* q;         // [2][B], [B], [2][B]
   float* dz2;                            // [2][B][HID]
   float* part; float* part_s; int nblk;  // [2][nblk][NSLOT][HID], [2][nblk][2] (sum dq, sum sq-err)
 };
 
 __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
-  __shared__ float red[4 * NSLOT * HID];
-  __shared__ float red_s[4][2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, net = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float cs[3 * 16 * HID];
+  __shared__ float sc[16][2];
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15, net = blockIdx.y;
+  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
   const float* Pn = p.P + net * p.p_ns;
-  const float4 wh = ld4(Pn + p.L.Wh + 4 * lane);
-  const float bh = Pn[p.L.bh];
-  float4 acc[3] = {f4(0.f), f4(0.f), f4(0.f)};
-  float s_dq = 0.f, s_loss = 0.f;
+  // loads first
+  const Row16 zt0 = row_ld(p.z2t + (long)bc * HID, sub), zt1 = row_ld(p.z2t + ((long)p.B + bc) * HID, sub);
+  const Row16 zo = row_ld(p.z2 + ((long)net * p.B + bc) * HID, sub);
+  const Row16 wt0 = row_ld(p.PT + p.L.Wh, sub), wt1 = row_ld(p.PT + p.p_ns + p.L.Wh, sub), wo = row_ld(Pn + p.L.Wh, sub);
+  Row16 gt0, bt0, gt1, bt1, go, bo;
+  if (p.ln) {
+    gt0 = row_ld(p.PT + p.L.g2, sub); bt0 = row_ld(p.PT + p.L.be2, sub);
+    gt1 = row_ld(p.PT + p.p_ns + p.L.g2, sub); bt1 = row_ld(p.PT + p.p_ns + p.L.be2, sub);
+    go = row_ld(Pn + p.L.g2, sub); bo = row_ld(Pn + p.L.be2, sub);
+  }
+  const float bht0 = p.PT[p.L.bh], bht1 = p.PT[p.p_ns + p.L.bh], bho = Pn[p.L.bh];
+  const float rw = p.rew[bc], dn = p.done[bc];
   const float alpha = p.sac ? expf(*p.log_alpha) : 0.f;
-  for (int it = 0; it < p.rpw; ++it) {
-    const int b = (blockIdx.x * 4 + wave) * p.rpw + it;
-    if (b >= p.B) break;
-    float qtv[2];
+  const float lpn = p.sac ? p.logp_next[bc] : 0.f;
+  Row16 xh, y, h; float rs;
+  ln_fwd(zt0, gt0, bt0, p.ln, xh, y, rs);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float* Pt = p.PT + i * p.p_ns;
-      float4 xh, yy; float mu, rs;
-      ln_row(ld4(p.z2t + ((long)i * p.B + b) * HID + 4 * lane), Pt + p.L.g2, Pt + p.L.be2, lane, p.ln, xh, yy, mu, rs);
-      qtv[i] = wave_sum(dot4(relu4(yy), ld4(Pt + p.L.Wh + 4 * lane))) + Pt[p.L.bh];
-    }
-    const float qmin = fminf(qtv[0], qtv[1]);
-    float qp = p.bcq ? 0.75f * qmin + 0.25f * fmaxf(qtv[0], qtv[1]) : qmin;
-    if (p.sac) qp -= alpha * p.logp_next[b];
-    const float yv = p.rew[b] + (1.0f - p.done[b]) * p.gamma * qp;
-    float4 xhat, yln; float mean, rstd;
-    ln_row(ld4(p.z2 + ((long)net * p.B + b) * HID + 4 * lane), Pn + p.L.g2, Pn + p.L.be2, lane, p.ln, xhat, yln, mean, rstd);
-    const float4 h = relu4(yln);
-    const float qv = wave_sum(dot4(h, wh)) + bh;
-    const float err = qv - yv;
-    const float dq = 2.0f * err / (float)p.B;
-    const float4 dy = gate4(wh * dq, yln);
-    const float4 dz = ln_row_bwd(dy, xhat, rstd, Pn + p.L.g2, lane, p.ln);
-    st4(p.dz2 + ((long)net * p.B + b) * HID + 4 * lane, dz);
-    acc[0] = acc[0] + dy * xhat; acc[1] = acc[1] + dy; acc[2] = acc[2] + h * dq;
-    s_dq += dq; s_loss += err * err;
-    if (lane == 0) {
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qt0 = row16_sum(row_dot(h, wt0)) + bht0;
+  ln_fwd(zt1, gt1, bt1, p.ln, xh, y, rs);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qt1 = row16_sum(row_dot(h, wt1)) + bht1;
+  const float qmin = fminf(qt0, qt1);
+  float qp = p.bcq ? 0.75f * qmin + 0.25f * fmaxf(qt0, qt1) : qmin;
+  if (p.sac) qp -= alpha * lpn;
+  const float yv = rw + (1.0f - dn) * p.gamma * qp;
+  float rstd;
+  ln_fwd(zo, go, bo, p.ln, xh, y, rstd);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qv = row16_sum(row_dot(h, wo)) + bho;
+  const float err = valid ? qv - yv : 0.f;
+  const float dq = 2.0f * err / (float)p.B;
+  Row16 dy, vals[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(wo.v[q] * dq, y.v[q]);
+  const Row16 dz = ln_bwd(dy, xh, rstd, go, p.ln);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; vals[2].v[q] = h.v[q] * dq; }
+  if (valid) {
+    row_st(p.dz2 + ((long)net * p.B + b) * HID, sub, dz);
+    if (sub == 0) {
       p.q[(long)net * p.B + b] = qv;
-      if (net == 0) { p.qt[b] = qtv[0]; p.qt[p.B + b] = qtv[1]; p.y[b] = yv; }
+      if (net == 0) { p.qt[b] = qt0; p.qt[p.B + b] = qt1; p.y[b] = yv; }
     }
   }
+  if (sub == 0) { sc[row][0] = dq; sc[row][1] = err * err; }
   const long blk = (long)net * p.nblk + blockIdx.x;
-  block_store_partials(red, acc, 3, p.part + blk * NSLOT * HID);
-  if (lane == 0) { red_s[wave][0] = s_dq; red_s[wave][1] = s_loss; }
-  __syncthreads();
-  if (threadIdx.x < 2)
-    p.part_s[blk * 2 + threadIdx.x] = (red_s[0][threadIdx.x] + red_s[1][threadIdx.x]) + (red_s[2][threadIdx.x] + red_s[3][threadIdx.x]);
+  block_colsum(cs, vals, 3, row, sub, p.part + blk * NSLOT * HID);   // (has the barrier that publishes sc)
+  if (t < 2) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += sc[i][t];
+    p.part_s[blk * 2 + t] = s;
+  }
 }
 
 struct ActorQTail {
   const float* z2c;                      // [nq][B][HID]
   const float* P; long p_ns; NetLayout L;// online critics
   const float* logp; const float* log_alpha;
-  int B, ln, sac, rpw;
+  int B, ln, sac;
   float* q; float* dz2;                  // [nq][B], [nq][B][HID]
   float* part_s; int nblk;               // [nblk][2]: loss partial in [.][1]
 };
 
 __global__ __launch_bounds__(256) void k_actorq_tail(ActorQTail p) {
-  __shared__ float red_s[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sc[16];
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15;
+  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
   const int nq = p.sac ? 2 : 1;
+  Row16 z[2], w[2], g[2], be[2], xh[2], y[2];
+  float rstd[2], qv[2] = {0.f, 0.f}, bh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i < nq) {
+      const float* Pn = p.P + i * p.p_ns;
+      z[i] = row_ld(p.z2c + ((long)i * p.B + bc) * HID, sub);
+      w[i] = row_ld(Pn + p.L.Wh, sub);
+      if (p.ln) { g[i] = row_ld(Pn + p.L.g2, sub); be[i] = row_ld(Pn + p.L.be2, sub); }
+      bh[i] = Pn[p.L.bh];
+    }
   const float alpha = p.sac ? expf(*p.log_alpha) : 0.f;
-  float s_loss = 0.f;
-  for (int it = 0; it < p.rpw; ++it) {
-    const int b = (blockIdx.x * 4 + wave) * p.rpw + it;
-    if (b >= p.B) break;
-    float4 xhat[2], yln[2]; float rstd[2], qv[2] = {0.f, 0.f};
+  const float lpv = p.sac ? p.logp[bc] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i < nq) {
-        const float* Pn = p.P + i * p.p_ns; float mu;
-        ln_row(ld4(p.z2c + ((long)i * p.B + b) * HID + 4 * lane), Pn + p.L.g2, Pn + p.L.be2, lane, p.ln, xhat[i], yln[i], mu, rstd[i]);
-        qv[i] = wave_sum(dot4(relu4(yln[i]), ld4(Pn + p.L.Wh + 4 * lane))) + Pn[p.L.bh];
+  for (int i = 0; i < 2; ++i)
+    if (i < nq) {
+      ln_fwd(z[i], g[i], be[i], p.ln, xh[i], y[i], rstd[i]);
+      Row16 h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h.v[q] = relu4(y[i].v[q]);
+      qv[i] = row16_sum(row_dot(h, w[i])) + bh[i];
+    }
+  const bool first = p.sac ? (qv[0] <= qv[1]) : true;
+  const float loss = p.sac ? (alpha * lpv - (first ? qv[0] : qv[1])) : -qv[0];
+  const float invB = 1.0f / (float)p.B;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i < nq) {
+      const float dq = ((i == 0) == first) ? -invB : 0.f;
+      Row16 dy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dy.v[q] = gate4(w[i].v[q] * dq, y[i].v[q]);
+      const Row16 dz = ln_bwd(dy, xh[i], rstd[i], g[i], p.ln);
+      if (valid) {
+        row_st(p.dz2 + ((long)i * p.B + b) * HID, sub, dz);
+        if (sub == 0) p.q[(long)i * p.B + b] = qv[i];
       }
     }
-    const bool first = p.sac ? (qv[0] <= qv[1]) : true;
-    s_loss += p.sac ? (alpha * p.logp[b] - (first ? qv[0] : qv[1])) : -qv[0];
-    const float invB = 1.0f / (float)p.B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i < nq) {
-        const float* Pn = p.P + i * p.p_ns;
-        const float dq = ((i == 0) == first) ? -invB : 0.f;
-        const float4 dy = gate4(ld4(Pn + p.L.Wh + 4 * lane) * dq, yln[i]);
-        const float4 dz = ln_row_bwd(dy, xhat[i], rstd[i], Pn + p.L.g2, lane, p.ln);
-        st4(p.dz2 + ((long)i * p.B + b) * HID + 4 * lane, dz);
-        if (lane == 0) p.q[(long)i * p.B + b] = qv[i];
-      }
-    }
-  }
-  if (lane == 0) red_s[wave] = s_loss;
+  if (sub == 0) sc[row] = valid ? loss : 0.f;
   __syncthreads();
-  if (threadIdx.x == 0) p.part_s[blockIdx.x * 2 + 1] = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+  if (t == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += sc[i];
+    p.part_s[blockIdx.x * 2 + 1] = s;
+  }
 }
 
-struct LnBwd {               // dz = LNbwd(relu'(.) * dh) for a hidden layer; optional (dgamma, dbeta) partials
-  const float* dh; long dh_ns; const float* z; long z_ns; const float* st; long st_ns; const float* h; long h_ns;
+struct LnBwd {               // dz = LNbwd(relu'(.) * dh) for hidden layer 1; optional (dgamma, dbeta) partials
+  const float* dh; const float* xh; const float* h; const float* rstd;   // [nets][B][HID] x3, [nets][B]
   const float* gamma; long p_ns;
-  int B, ln, rpw, want_part;
-  float* dz; long dz_ns;
+  int B, ln, want_part;
+  float* dz;
   float* part; int nblk;
 };
 
 __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
-  __shared__ float red[4 * NSLOT * HID];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, net = blockIdx.y;
-  const float* g = p.gamma + net * p.p_ns;
-  float4 acc[2] = {f4(0.f), f4(0.f)};
-  for (int it = 0; it < p.rpw; ++it) {
-    const int b = (blockIdx.x * 4 + wave) * p.rpw + it;
-    if (b >= p.B) break;
-    const long ro = (long)b * HID + 4 * lane;
-    const float4 dy = gate4(ld4(p.dh + net * p.dh_ns + ro), ld4(p.h + net * p.h_ns + ro));
-    float4 xhat = f4(0.f); float rstd = 1.f;
-    if (p.ln) {
-      const float* st = p.st + net * p.st_ns + 2 * (long)b;
-      rstd = st[1];
-      xhat = (ld4(p.z + net * p.z_ns + ro) - f4(st[0])) * rstd;
-    }
-    st4(p.dz + net * p.dz_ns + ro, ln_row_bwd(dy, xhat, rstd, g, lane, p.ln));
-    acc[0] = acc[0] + dy * xhat; acc[1] = acc[1] + dy;
+  __shared__ __attribute__((aligned(16))) float cs[2 * 16 * HID];
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15, net = blockIdx.y;
+  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
+  const long ro = ((long)net * p.B + bc) * HID;
+  const Row16 dh = row_ld(p.dh + ro, sub), hh = row_ld(p.h + ro, sub), xh = row_ld(p.xh + ro, sub);
+  Row16 g;
+  if (p.ln) g = row_ld(p.gamma + net * p.p_ns, sub);
+  const float rstd = p.ln ? p.rstd[(long)net * p.B + bc] : 1.f;
+  Row16 dy, vals[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { dy.v[q] = gate4(dh.v[q], hh.v[q]); if (!valid) dy.v[q] = f4(0.f); }
+  const Row16 dz = ln_bwd(dy, xh, rstd, g, p.ln);
+  if (valid) row_st(p.dz + ((long)net * p.B + b) * HID, sub, dz);
+  if (p.want_part) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
+    block_colsum(cs, vals, 2, row, sub, p.part + ((long)net * p.nblk + blockIdx.x) * NSLOT * HID);
   }
-  if (p.want_part)
-    block_store_partials(red, acc, 2, p.part + ((long)net * p.nblk + blockIdx.x) * NSLOT * HID);
 }
 
 struct ActorHeadBwd {
   const float* dA; long dA_ns; int ldA; int nq;   // [nq][B][ldA] grads wrt the action from each critic
   const float* tg; int a4; const float* eps; const float* log_alpha; const float* scale;
   const float* P; NetLayout L;
-  const float* z2; const float* st2; const float* h2;
-  int B, a, ln, sac, rpw;
+  const float* xh2; const float* rstd2; const float* h2;
+  int B, a, ln, sac;
   float* du; int ldu;                    // [B][ldu] grad wrt head outputs
   float* dz2;                            // [B][HID]
   float* part; int nblk;                 // [nblk][NSLOT][HID]
 };
 
 __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
-  __shared__ float red[4 * NSLOT * HID];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float cs[2 * 16 * HID];   // also holds dh2 [16][AS] before the column sums
+  __shared__ __attribute__((aligned(16))) float Du[16 * 68];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row = t >> 4, sub = t & 15, r = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
+  const int nh = p.L.nh, C = (nh + 15) >> 4;      // k chunks of the head-backward product (<= 4)
   const float* Wh = p.P + p.L.Wh;
-  float4 acc[2] = {f4(0.f), f4(0.f)};
-  const float dlogp = p.sac ? expf(*p.log_alpha) / (float)p.B : 0.f;
-  for (int it = 0; it < p.rpw; ++it) {
-    const int b = (blockIdx.x * 4 + wave) * p.rpw + it;
-    if (b >= p.B) break;
-    float g_mean = 0.f, g_raw = 0.f;
-    if (lane < p.a) {
-      const int j = lane;
-      float dAj = p.dA[(long)b * p.ldA + j];
-      if (p.nq == 2) dAj += p.dA[p.dA_ns + (long)b * p.ldA + j];
-      const float sc = p.scale[j];
-      const float* tg = p.tg + (long)b * 4 * p.a4;
-      if (p.sac) {
-        const float t = tg[j], sd = tg[p.a4 + j], yt = tg[2 * p.a4 + j], e = p.eps[(long)b * p.a + j];
-        const float omy2 = 1.0f - yt * yt;
-        const float g0 = dAj * sc * omy2 + dlogp * (2.0f * sc * yt * omy2) / (sc * omy2 + 1e-6f);
-        g_mean = g0;
-        g_raw = (g0 * e * sd - dlogp) * 3.5f * (1.0f - t * t);
-        p.du[(long)b * p.ldu + j] = g_mean;
-        p.du[(long)b * p.ldu + p.a + j] = g_raw;
-      } else {
-        const float th = tg[j];
-        g_mean = dAj * sc * (1.0f - th * th);
-        p.du[(long)b * p.ldu + j] = g_mean;
+  // loads first
+  const long ro = (long)bc * HID;
+  const Row16 hh = row_ld(p.h2 + ro, sub), xh = row_ld(p.xh2 + ro, sub);
+  Row16 g;
+  if (p.ln) g = row_ld(p.P + p.L.g2, sub);
+  const float rstd = p.ln ? p.rstd2[bc] : 1.f;
+  float4 wf[4][4];                       // B operand of dh2 = du Wh: Wh[k = 16c + 4kq + jj][n = (4*tt + wave)*16 + r]
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = (4 * tt + wave) * 16 + r, k = 16 * c + 4 * kq;
+      wf[tt][c] = f4(0.f);
+      if (c < C) {
+        if (k < nh) wf[tt][c].x = Wh[(long)k * HID + n];
+        if (k + 1 < nh) wf[tt][c].y = Wh[(long)(k + 1) * HID + n];
+        if (k + 2 < nh) wf[tt][c].z = Wh[(long)(k + 2) * HID + n];
+        if (k + 3 < nh) wf[tt][c].w = Wh[(long)(k + 3) * HID + n];
       }
     }
-    float4 dh = f4(0.f);
-    for (int j = 0; j < p.a; ++j) {
-      dh = dh + ld4(Wh + (long)j * HID + 4 * lane) * __shfl(g_mean, j);
-      if (p.sac) dh = dh + ld4(Wh + (long)(p.a + j) * HID + 4 * lane) * __shfl(g_raw, j);
+  for (int j = sub; j < 64; j += 16) Du[row * 68 + j] = 0.f;
+  __syncthreads();
+  const float dlogp = p.sac ? expf(*p.log_alpha) / (float)p.B : 0.f;
+  for (int j = sub; j < p.a; j += 16) {
+    float dAj = p.dA[(long)bc * p.ldA + j];
+    if (p.nq == 2) dAj += p.dA[p.dA_ns + (long)bc * p.ldA + j];
+    const float sc = p.scale[j];
+    const float* tg = p.tg + (long)bc * 4 * p.a4;
+    float g_mean, g_raw = 0.f;
+    if (p.sac) {
+      const float tt = tg[j], sd = tg[p.a4 + j], yt = tg[2 * p.a4 + j], e = p.eps[(long)bc * p.a + j];
+      const float omy2 = 1.0f - yt * yt;
+      const float g0 = dAj * sc * omy2 + dlogp * (2.0f * sc * yt * omy2) / (sc * omy2 + 1e-6f);
+      g_mean = g0;
+      g_raw = (g0 * e * sd - dlogp) * 3.5f * (1.0f - tt * tt);
+    } else {
+      const float th = tg[j];
+      g_mean = dAj * sc * (1.0f - th * th);
     }
-    const long ro = (long)b * HID + 4 * lane;
-    const float4 dy = gate4(dh, ld4(p.h2 + ro));
-    float4 xhat = f4(0.f); float rstd = 1.f;
-    if (p.ln) { rstd = p.st2[2 * b + 1]; xhat = (ld4(p.z2 + ro) - f4(p.st2[2 * b])) * rstd; }
-    st4(p.dz2 + ro, ln_row_bwd(dy, xhat, rstd, p.P + p.L.g2, lane, p.ln));
-    acc[0] = acc[0] + dy * xhat; acc[1] = acc[1] + dy;
+    if (!valid) { g_mean = 0.f; g_raw = 0.f; }
+    Du[row * 68 + j] = g_mean;
+    if (p.sac) Du[row * 68 + p.a + j] = g_raw;
+    if (valid) {
+      p.du[(long)b * p.ldu + j] = g_mean;
+      if (p.sac) p.du[(long)b * p.ldu + p.a + j] = g_raw;
+    }
   }
-  block_store_partials(red, acc, 2, p.part + (long)blockIdx.x * NSLOT * HID);
+  __syncthreads();
+  // dh2[16][256] = du[16][nh] Wh[nh][256]; wave w owns column tiles w, w+4, w+8, w+12
+  float* DH = cs;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) { const float4 av = ld4(Du + r * 68 + 16 * c + 4 * kq); MFMA4(acc, av, wf[tt][c]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) DH[(4 * kq + i) * AS + (4 * tt + wave) * 16 + r] = acc[i];
+  }
+  __syncthreads();
+  const Row16 dh = row_ld(DH + row * AS, sub);
+  __syncthreads();                       // DH is reused by the column sums below
+  Row16 dy, vals[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(dh.v[q], hh.v[q]);
+  const Row16 dz = ln_bwd(dy, xh, rstd, g, p.ln);
+  if (valid) row_st(p.dz2 + (long)b * HID, sub, dz);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
+  block_colsum(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
 }
 
 // ------------------------------------------------------------------------------------------------ optimiser
