@@ -149,7 +149,7 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
 static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const NtArgs& g, int nets) {
-  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.N + 63) / 64)), 1, (unsigned)nets);
+  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.N + 15) / 16)), 1, (unsigned)nets);
   if (fuse1) {
     if (pro == 1) hipLaunchKernelGGL((k_nt<1, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_nt<2, true>), grid, dim3(256), 0, s, g);
@@ -162,13 +162,13 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
   return 0;
 }
 static int launch_nn(sactd3_engine* e, hipStream_t s, const NnArgs& g, int nets) {
-  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 63) / 64)), 1, (unsigned)nets);
+  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 15) / 16)), 1, (unsigned)nets);
   hipLaunchKernelGGL(k_nn, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
 static int launch_tn(sactd3_engine* e, hipStream_t s, const TnArgs& g, int nets) {
-  const dim3 grid((unsigned)(((g.N + 15) / 16) * ((g.ldw + 63) / 64)), 1, (unsigned)nets);
+  const dim3 grid((unsigned)(((g.N + 15) / 16) * ((g.ldw + 15) / 16)), 1, (unsigned)nets);
   hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;

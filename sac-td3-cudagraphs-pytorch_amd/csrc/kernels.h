@@ -32,6 +32,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (tools/kprobe.hip): shader-clock stamps of the LAST block's thread 0 at phase boundaries.
+#ifdef SACTD3_STAMPS
+__device__ long long g_stamps[16];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0) { __builtin_amdgcn_s_waitcnt(0); g_stamps[i] = clock64(); } } while (0)
+#else
+#define STAMP(i)
+#endif
+
 struct DevCtl {
   unsigned long long seed;
   int sample_ctr;     // bumped after every index draw
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).z, (b).z, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).w, (b).w, acc, 0, 0, 0);
 
-struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = 16 rows x 64 cols
+struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = one 16 x 16 output tile, K split over the 4 waves
   const float* A; int lda; long a_ns;       // !FUSE1: input rows
   const float* Wt; int ldw; const float* bias; long p_ns;   // W = Wt + net*p_ns, [N][ldw]
   const float* gamma; const float* beta;    // LN affine applied to the A rows (PRO == 1)
@@ -251,146 +259,168 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int M, N, K;                              // PRO != 0 or FUSE1: K == 256
   // FUSE1: A rows = x W1^T + b1 computed here (x: [M][ldx], K1 <= 64)
   const float* X; int ldx; long x_ns; int K1; const float* W1; int ldw1; const float* b1;
-  // optional stores of the prologue's rows by the column-strip-0 blocks (all [M][256] / [M], net stride act_ns / M)
+  // optional stores of the prologue's rows by the column-tile-0 blocks (all [M][256] / [M], net stride act_ns / M)
   float* xh_out; float* h_out; float* rstd_out; long act_ns;
   int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
 };
 
+// Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
+__device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 acc, int wave, int lane) {
+  st4(red + (wave * 64 + lane) * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  __syncthreads();
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    const float4 a = ld4(red + lane * 4), b = ld4(red + (64 + lane) * 4), c = ld4(red + (128 + lane) * 4), d = ld4(red + (192 + lane) * 4);
+    o[0] = (a.x + b.x) + (c.x + d.x); o[1] = (a.y + b.y) + (c.y + d.y);
+    o[2] = (a.z + b.z) + (c.z + d.z); o[3] = (a.w + b.w) + (c.w + d.w);
+  }
+  return o;
+}
+
 // PRO: 0 none, 1 LayerNorm+ReLU, 2 ReLU.  FUSE1: the A rows are produced by a fused first layer.
+// No LDS staging: every operand is loaded from global memory straight into its MFMA fragment registers, all loads
+// of a wave issued back to back (each block pulls ~32 KB; the per-CU fetch rate is what bounds these kernels).
 template <int PRO, bool FUSE1>
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[16 * AS];
-  __shared__ __attribute__((aligned(16))) float Ws[64 * AS];
+  __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float stat[16 * 36];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
     if (p.tick0) *p.tick0 += 1;
     if (p.tick1) *p.tick1 += 1;
   }
-  const int strips = (p.N + 63) >> 6;
-  const int tm = blockIdx.x / strips, strip = blockIdx.x % strips;
-  const int m0 = tm * 16, n0 = strip * 64;
-  const float* Wn = p.Wt + net * p.p_ns;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-
-  for (int k0 = 0; k0 < p.K; k0 += 256) {     // one pass unless an unfused first layer is wider than 256
-    int kc = 16;                                 // chunk width: power of two in [16, 256] (zero-filled beyond K)
-    while (kc < 256 && kc < p.K - k0) kc <<= 1;
-    const int kc4 = kc >> 2, ksh = 31 - __clz(kc4);
-    if (k0) __syncthreads();
-    // ---- 1. every global load of this pass, issued back to back
-    float4 vw[16];
+  const int tiles_n = (p.N + 15) >> 4;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int mrow = min(m0 + r, p.M - 1), nrow = min(n0 + r, p.N - 1);
+  const float* Wrow = p.Wt + net * p.p_ns + (long)nrow * p.ldw;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  STAMP(0);
+  if (PRO != 0 || FUSE1) {                 // K == 256: wave w owns k in [64 w, 64 w + 64)
+    const int kb = 64 * wave + 4 * kq;
+    float4 wv[4], av[4], gv[4], bv[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = t + 256 * u;
-      const int row = i >> ksh, c4 = i & (kc4 - 1), k = k0 + 4 * c4, n = n0 + row;
-      vw[u] = f4(0.f);
-      if (row < 64 && n < p.N && k < p.K) vw[u] = zero_beyond(ld4(Wn + (long)n * p.ldw + k), k, p.K);
-    }
-    float4 va[4];
-    Row16 g, be;
+    for (int c = 0; c < 4; ++c) wv[c] = ld4(Wrow + kb + 16 * c);
     if (PRO == 1) {
-      g = row_ld(p.gamma + net * p.p_ns, t & 15); be = row_ld(p.beta + net * p.p_ns, t & 15);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { gv[c] = ld4(p.gamma + net * p.p_ns + kb + 16 * c); bv[c] = ld4(p.beta + net * p.p_ns + kb + 16 * c); }
     }
     if (!FUSE1) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = t + 256 * u;
-        const int row = i >> ksh, c4 = i & (kc4 - 1), k = k0 + 4 * c4, m = m0 + row;
-        va[u] = f4(0.f);
-        if (row < 16 && m < p.M && k < p.K) va[u] = zero_beyond(ld4(p.A + net * p.a_ns + (long)m * p.lda + k), k, p.K);
-      }
+      for (int c = 0; c < 4; ++c) av[c] = ld4(p.A + net * p.a_ns + (long)mrow * p.lda + kb + 16 * c);
     } else {
-      // first layer, transposed product so that a lane ends up with 4 consecutive columns of one row:
-      // D[i = n][j = m] = sum_k W1[n][k] x[m][k]; wave w owns column tiles w, w+4, w+8, w+12
-      const int C1 = (p.K1 + 15) >> 4;      // <= 4
-      const int mx = min(m0 + r, p.M - 1);
-      float4 xv[4], wv[4][4];
+      // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
+      // z1[m][64 w + 16 c + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer
+      const int C1 = (p.K1 + 15) >> 4;     // <= 4
+      float4 xv[4], w1[4][4], b1v[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 16 * c + 4 * kq;
-        xv[c] = f4(0.f);
-        if (c < C1 && k < p.K1) xv[c] = zero_beyond(ld4(p.X + net * p.x_ns + (long)mx * p.ldx + k), k, p.K1);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          wv[tt][c] = f4(0.f);
-          if (c < C1 && k < p.K1)
-            wv[tt][c] = zero_beyond(ld4(p.W1 + net * p.p_ns + (long)((wave + 4 * tt) * 16 + r) * p.ldw1 + k), k, p.K1);
-        }
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int c1 = 0; c1 < 4; ++c1) {
+        const int k = 16 * c1 + 4 * kq;
+        const bool on = c1 < C1 && k < p.K1;
+        xv[c1] = on ? zero_beyond(ld4(p.X + net * p.x_ns + (long)mrow * p.ldx + k), k, p.K1) : f4(0.f);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (c < C1) { MFMA4(z, wv[tt][c], xv[c]); }
-        const int col = (wave + 4 * tt) * 16 + 4 * kq;      // lane (m = r, kq): z[reg] = z1[m][col + reg]
-        const float4 b1 = ld4(p.b1 + net * p.p_ns + col);
-        st4(As + r * AS + col, make_float4(z[0] + b1.x, z[1] + b1.y, z[2] + b1.z, z[3] + b1.w));
+          w1[c][c1] = on ? zero_beyond(ld4(p.W1 + net * p.p_ns + (long)(64 * wave + 16 * c + r) * p.ldw1 + k), k, p.K1) : f4(0.f);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b1v[c] = ld4(p.b1 + net * p.p_ns + kb + 16 * c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c1 = 0; c1 < 4; ++c1)
+          if (c1 < C1) { MFMA4(z, w1[c][c1], xv[c1]); }
+        av[c] = make_float4(z[0] + b1v[c].x, z[1] + b1v[c].y, z[2] + b1v[c].z, z[3] + b1v[c].w);
       }
     }
-    // ---- 2. park in LDS
+    __builtin_amdgcn_sched_barrier(0);     // keep every load above issued before anything below is scheduled
+    STAMP(1);
+    float4 xh[4];
+    float rstd = 1.f;
+    if (PRO == 1) {
+      // row statistics: this lane holds 16 of the row's 256 values; combine the 16 (mean, M2) partials (Chan et al.)
+      float ml = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = t + 256 * u;
-      const int row = i >> ksh, c4 = i & (kc4 - 1);
-      if (row < 64) st4(Ws + row * AS + 4 * c4, vw[u]);
-    }
-    if (!FUSE1) {
+      for (int c = 0; c < 4; ++c) ml += sum4(av[c]);
+      ml *= (1.0f / 16.0f);
+      float m2 = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = t + 256 * u;
-        const int row = i >> ksh, c4 = i & (kc4 - 1);
-        if (row < 16) st4(As + row * AS + 4 * c4, va[u]);
-      }
-    }
-    __syncthreads();
-    // ---- 3. prologue on the A rows (16 threads per row)
-    if (PRO != 0) {
-      const int row = t >> 4, sub = t & 15;
-      const Row16 z = row_ld(As + row * AS, sub);
-      Row16 xh, y;
-      float rstd = 1.f;
-      if (PRO == 1) ln_fwd(z, g, be, 1, xh, y, rstd); else { xh = z; y = z; }
-      Row16 h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
-      row_st(As + row * AS, sub, h);
-      const int m = m0 + row;
-      if (strip == 0 && m < p.M) {
-        if (p.xh_out) row_st(p.xh_out + net * p.act_ns + (long)m * HID, sub, xh);
-        if (p.h_out) row_st(p.h_out + net * p.act_ns + (long)m * HID, sub, h);
-        if (p.rstd_out && sub == 0) p.rstd_out[(long)net * p.M + m] = rstd;
-      }
+      for (int c = 0; c < 4; ++c) { const float4 d = av[c] - f4(ml); m2 += dot4(d, d); }
+      stat[r * 36 + (wave * 4 + kq) * 2] = ml;
+      stat[r * 36 + (wave * 4 + kq) * 2 + 1] = m2;
       __syncthreads();
-    }
-    // ---- 4. MFMA: wave w -> output columns n0 + 16 w .. +15
-    const int chunks = kc >> 4;
-    const float* arow = As + r * AS + 4 * kq;
-    const float* wrow = Ws + (wave * 16 + r) * AS + 4 * kq;
-#pragma unroll 4
-    for (int c = 0; c < chunks; c += 2) {
-      const float4 a0 = ld4(arow + 16 * c), w0 = ld4(wrow + 16 * c);
-      MFMA4(acc0, a0, w0);
-      if (c + 1 < chunks) {
-        const float4 a1 = ld4(arow + 16 * c + 16), w1 = ld4(wrow + 16 * c + 16);
-        MFMA4(acc1, a1, w1);
+      float4 s[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = ld4(stat + r * 36 + 4 * i);    // (mean, M2) x 2 per float4
+      float mean = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mean += s[i].x + s[i].z;
+      mean *= (1.0f / 16.0f);
+      float M2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d0 = s[i].x - mean, d1 = s[i].z - mean;
+        M2 += (s[i].y + s[i].w) + 16.0f * (d0 * d0 + d1 * d1);
       }
+      rstd = 1.0f / sqrtf(M2 * (1.0f / HID) + LN_EPS);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xh[c] = (av[c] - f4(mean)) * rstd; av[c] = relu4(xh[c] * gv[c] + bv[c]); }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xh[c] = av[c]; av[c] = relu4(av[c]); }
     }
+    STAMP(2);
+    if (tn == 0 && m0 + r < p.M) {
+      const long ro = net * p.act_ns + (long)(m0 + r) * HID + kb;
+      if (p.xh_out) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) st4(p.xh_out + ro + 16 * c, xh[c]);
+      }
+      if (p.h_out) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) st4(p.h_out + ro + 16 * c, av[c]);
+      }
+      if (p.rstd_out && wave == 0 && kq == 0) p.rstd_out[(long)net * p.M + m0 + r] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { MFMA4(acc, av[c], wv[c]); }
+  } else {                                   // generic K (an unfused first layer): wave w takes k chunks w, w+4, ...
+    const float* Arow = p.A + net * p.a_ns + (long)mrow * p.lda;
+    const int chunks = (p.K + 15) >> 4;
+    for (int cb = 0; cb < chunks; cb += 32) {
+      float4 a[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = cb + wave + 4 * u, k = 16 * c + 4 * kq;
+        const bool on = c < chunks && k < p.K;
+        a[u] = on ? zero_beyond(ld4(Arow + k), k, p.K) : f4(0.f);
+        w[u] = on ? zero_beyond(ld4(Wrow + k), k, p.K) : f4(0.f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { MFMA4(acc, a[u], w[u]); }
+    }
+    STAMP(1); STAMP(2);
   }
-  const int col = n0 + wave * 16 + (lane & 15);
-  if (col < p.N) {
-    const float bv = p.bias ? p.bias[net * p.p_ns + col] : 0.f;
+  STAMP(3);
+  acc = splitk_reduce(red, acc, wave, lane);
+  STAMP(4);
+  const int col = n0 + (lane & 15);
+  if (wave == 0 && col < p.N) {
+    const float bias = p.bias ? p.bias[net * p.p_ns + col] : 0.f;
     float* y = p.Y + net * p.y_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 4 * (lane >> 4) + i;
-      if (row < p.M) y[(long)row * p.ldy + col] = (acc0[i] + acc1[i]) + bv;
+      if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bias;
     }
   }
+  STAMP(5);
 }
 
-struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout] ; block = 16 rows x 64 cols
+struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout] ; block = one 16 x 16 tile, n split over waves
   const float* dY; long dy_ns;              // row stride HID
   const float* Wt; int ldw; long p_ns; int k_off;
   float* dX; int ldx; long dx_ns;
@@ -398,68 +428,45 @@ struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Ko
 };
 
 __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
-  __shared__ __attribute__((aligned(16))) float Ds[16 * AS];
-  __shared__ __attribute__((aligned(16))) float Wn[HID * WS];
+  __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  const int strips = (p.Kout + 63) >> 6;
-  const int tm = blockIdx.x / strips, strip = blockIdx.x % strips;
-  const int m0 = tm * 16, c0 = strip * 64;          // c0: first output column of this block
-  const float* W = p.Wt + net * p.p_ns + p.k_off;
-  float4 va[4];
+  const int tiles_k = (p.Kout + 15) >> 4;
+  const int tm = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int m0 = tm * 16, k0 = tk * 16;
+  const int mrow = min(m0 + r, p.M - 1);
+  const int nb = 64 * wave + 4 * kq;
+  const float* Drow = p.dY + net * p.dy_ns + (long)mrow * HID + nb;
+  const float* Wc = p.Wt + net * p.p_ns + (long)nb * p.ldw + p.k_off + min(k0 + r, p.Kout - 1);
+  STAMP(0);
+  float4 av[4], bv[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = t + 256 * u, row = i >> 6, c4 = i & 63, m = m0 + row;
-    va[u] = m < p.M ? ld4(p.dY + net * p.dy_ns + (long)m * HID + 4 * c4) : f4(0.f);
+  for (int c = 0; c < 4; ++c) {
+    av[c] = ld4(Drow + 16 * c);
+    const float* w = Wc + (long)(16 * c) * p.ldw;
+    bv[c] = make_float4(w[0], w[p.ldw], w[2 * (long)p.ldw], w[3 * (long)p.ldw]);
   }
-  if (((p.k_off | p.ldw) & 3) == 0) {           // 16-byte aligned strip: 16 float4 per thread
-    float4 vw[16];
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = t + 256 * u, n = i >> 4, c4 = i & 15, col = c0 + 4 * c4;
-      vw[u] = col < p.Kout ? zero_beyond(ld4(W + (long)n * p.ldw + col), col, p.Kout) : f4(0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = t + 256 * u, n = i >> 4, c4 = i & 15;
-      st4(Wn + n * WS + 4 * c4, vw[u]);
-    }
-  } else {                                      // narrow unaligned slice (dQ/da: columns o .. o+a of W1)
-    for (int i = t; i < HID * 64; i += 256) {
-      const int n = i >> 6, cc = i & 63, col = c0 + cc;
-      Wn[n * WS + cc] = col < p.Kout ? W[(long)n * p.ldw + col] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = t + 256 * u, row = i >> 6, c4 = i & 63;
-    st4(Ds + row * AS + 4 * c4, va[u]);
-  }
-  __syncthreads();
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = Ds + r * AS + 4 * kq;
-  const float* wcol = Wn + (4 * kq) * WS + wave * 16 + r;
-#pragma unroll 4
-  for (int c = 0; c < 16; c += 2) {
-    const float4 a0 = ld4(arow + 16 * c), a1 = ld4(arow + 16 * c + 16);
-    const float* w0 = wcol + (16 * c) * WS; const float* w1 = w0 + 16 * WS;
-    const float4 b0 = make_float4(w0[0], w0[WS], w0[2 * WS], w0[3 * WS]);
-    const float4 b1 = make_float4(w1[0], w1[WS], w1[2 * WS], w1[3 * WS]);
-    MFMA4(acc0, a0, b0);
-    MFMA4(acc1, a1, b1);
-  }
-  const int col = c0 + wave * 16 + (lane & 15);
-  if (col < p.Kout) {
+  for (int c = 0; c < 4; ++c) { MFMA4(acc, av[c], bv[c]); }
+  STAMP(2);
+  acc = splitk_reduce(red, acc, wave, lane);
+  STAMP(3);
+  const int col = k0 + (lane & 15);
+  if (wave == 0 && col < p.Kout) {
     float* x = p.dX + net * p.dx_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 4 * (lane >> 4) + i;
-      if (row < p.M) x[(long)row * p.ldx + col] = acc0[i] + acc1[i];
+      if (row < p.M) x[(long)row * p.ldx + col] = acc[i];
     }
   }
+  STAMP(4);
 }
 
-struct TnArgs {              // dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 written as 0); block = 16 rows(n) x 64 cols(k)
+struct TnArgs {              // dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 written as 0); block = one 16 x 16 tile, m split over waves
   const float* dY; int ldy; long dy_ns; int N;
   const float* X; int ldx; long x_ns; int K;
   float* dW; int ldw;
@@ -472,71 +479,49 @@ struct TnArgs {              // dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-
 };
 
 __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
-  __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
-  __shared__ __attribute__((aligned(16))) float Xs[256 * WS];
-  __shared__ float red[16 * 17];
+  __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+  __shared__ float cred[16 * 17];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  const int strips = (p.ldw + 63) >> 6;
-  const int tn = blockIdx.x / strips, strip = blockIdx.x % strips;
-  const int n0 = tn * 16, c0 = strip * 64;
-  const float* dY = p.dY + net * p.dy_ns;
-  const float* X = p.X + net * p.x_ns;
-  const int Kr = (p.K + 3) & ~3;          // rows of X hold at least round4(K) floats
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
-  for (int mb = 0; mb < p.M; mb += 256) {
-    if (mb) __syncthreads();
-    float4 vy[4], vx[16];
-    const bool yal = ((p.ldy & 3) == 0) && n0 + 16 <= ((p.N + 3) & ~3);
+  const int tiles_k = (p.ldw + 15) >> 4;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * 16, k0 = tk * 16;
+  const float* Dc = p.dY + net * p.dy_ns + min(n0 + r, p.N - 1);
+  const bool kval = k0 + r < p.K;
+  const float* Xc = p.X + net * p.x_ns + min(k0 + r, p.K - 1);
+  const int chunks = (p.M + 15) >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;
+  for (int cb = 0; cb < chunks; cb += 16) {       // per batch: 4 chunks of 16 rows per wave, 32 loads in flight per lane
+    float4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4;
-      vy[u] = f4(0.f);
-      if (m < p.M) {
-        const float* src = dY + (long)m * p.ldy + n;
-        if (yal) vy[u] = zero_beyond(ld4(src), n, p.N);
-        else { if (n < p.N) vy[u].x = src[0]; if (n + 1 < p.N) vy[u].y = src[1]; if (n + 2 < p.N) vy[u].z = src[2]; if (n + 3 < p.N) vy[u].w = src[3]; }
+      const int c = cb + wave + 4 * u;
+      float* ap = &a[u].x; float* bp = &b[u].x;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int m = 16 * c + 4 * kq + jj;
+        const bool on = c < chunks && m < p.M;
+        const int mc = on ? m : 0;
+        const float av = Dc[(long)mc * p.ldy], xv = Xc[(long)mc * p.ldx];
+        ap[jj] = on ? av : 0.f;
+        bp[jj] = (on && kval) ? xv : 0.f;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = t + 256 * u, row = i >> 4, c4 = i & 15, m = mb + row, k = c0 + 4 * c4;
-      vx[u] = (m < p.M && k < Kr) ? zero_beyond(ld4(X + (long)m * p.ldx + k), k, p.K) : f4(0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = t + 256 * u; st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]); }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { const int i = t + 256 * u; st4(Xs + (i >> 4) * WS + 4 * (i & 15), vx[u]); }
-    __syncthreads();
-    const float* ycol = Ys + (4 * kq) * YS + r;
-    const float* xcol = Xs + (4 * kq) * WS + wave * 16 + r;
-#pragma unroll 4
-    for (int c = 0; c < 16; c += 2) {
-      const float* y0 = ycol + (16 * c) * YS; const float* y1 = y0 + 16 * YS;
-      const float* x0 = xcol + (16 * c) * WS; const float* x1 = x0 + 16 * WS;
-      const float4 a0 = make_float4(y0[0], y0[YS], y0[2 * YS], y0[3 * YS]);
-      const float4 b0 = make_float4(x0[0], x0[WS], x0[2 * WS], x0[3 * WS]);
-      const float4 a1 = make_float4(y1[0], y1[YS], y1[2 * YS], y1[3 * YS]);
-      const float4 b1 = make_float4(x1[0], x1[WS], x1[2 * WS], x1[3 * WS]);
-      MFMA4(acc0, a0, b0);
-      MFMA4(acc1, a1, b1);
-    }
-    if (strip == 0 && p.dbias) {
-      const int col = t & 15, part = t >> 4;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) bsum += Ys[(part * 16 + i) * YS + col];
-    }
+    for (int u = 0; u < 4; ++u) { asum += sum4(a[u]); MFMA4(acc, a[u], b[u]); }
   }
-  if (strip == 0) {
-    const int col = t & 15, part = t >> 4, n = n0 + col;
+  acc = splitk_reduce(red, acc, wave, lane);
+  if (tk == 0) {
+    const int col = t & 15, part = t >> 4, n = n0 + col;     // (col, part) == (r, 4 wave + kq)
     if (p.dbias) {
-      red[part * 17 + col] = bsum;
+      cred[part * 17 + col] = asum;
       __syncthreads();
       if (t < 16 && n < p.N) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += red[i * 17 + t];
+        for (int i = 0; i < 16; ++i) s += cred[i * 17 + t];
         p.dbias[net * p.g_ns + n] = s;
       }
     }
@@ -546,29 +531,29 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
         for (int blk = part; blk < p.nblk; blk += 16)
           s += p.part[(((long)net * p.nblk + blk) * NSLOT + p.fin_slot[e]) * HID + n];
       __syncthreads();
-      red[part * 17 + col] = s;
+      cred[part * 17 + col] = s;
       __syncthreads();
       if (t < 16 && n < p.N) {
-        float a = 0.f;
+        float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a += red[i * 17 + t];
-        p.fin_dst[e][net * p.g_ns + n] = a;
+        for (int i = 0; i < 16; ++i) v += cred[i * 17 + t];
+        p.fin_dst[e][net * p.g_ns + n] = v;
       }
     }
-    if (p.fin_s && tn == 0 && wave == 0) {
+    if (p.fin_s && tn == 0 && wave == 1) {
       float s = 0.f;
       for (int blk = lane; blk < p.nblk; blk += 64) s += p.part_s[((long)net * p.nblk + blk) * 2];
       s = wave_sum(s);
       if (lane == 0) p.fin_s[net * p.g_ns] = s;
     }
   }
-  const int col = c0 + wave * 16 + (lane & 15);
-  if (col < p.ldw) {
+  const int col = k0 + (lane & 15);
+  if (wave == 0 && col < p.ldw) {
     float* w = p.dW + net * p.g_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = n0 + 4 * (lane >> 4) + i;
-      if (row < p.N) w[(long)row * p.ldw + col] = (col < p.K) ? acc0[i] + acc1[i] : 0.f;
+      if (row < p.N) w[(long)row * p.ldw + col] = (col < p.K) ? acc[i] : 0.f;
     }
   }
 }

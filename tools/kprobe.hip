@@ -1,0 +1,62 @@
+// Diagnostic harness (not product): runs single kernels of csrc/kernels.h at the bench shapes with in-kernel
+// phase stamps (SACTD3_STAMPS) and host-side per-launch times inside a captured graph.
+#define SACTD3_STAMPS 1
+#include "../sac-td3-cudagraphs-pytorch_amd/csrc/kernels.h"
+#include <chrono>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <class F> static double graph_us(hipStream_t s, F&& launch, int n_in_graph, int reps) {
+  hipGraph_t g; hipGraphExec_t ge;
+  hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  for (int i = 0; i < n_in_graph; ++i) launch();
+  hipStreamEndCapture(s, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  for (int i = 0; i < 5; ++i) hipGraphLaunch(ge, s);
+  hipStreamSynchronize(s);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; ++i) hipGraphLaunch(ge, s);
+  hipStreamSynchronize(s);
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps / n_in_graph;
+  hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  return us;
+}
+static void show(const char* name, double us, int n) {
+  long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
+  printf("%-22s %6.2f us/launch | last block phases (cycles):", name, us);
+  for (int i = 1; i < n; ++i) printf(" %lld", h[i] - h[i - 1]);
+  printf("  total %lld\n", h[n - 1] - h[0]);
+}
+
+int main() {
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const int B = 256, o = 11, a = 3, ldc = 16;
+  float *X, *P, *Z2, *Y, *DX, *XH, *H, *RS;
+  CK(hipMalloc(&X, B * ldc * 4)); CK(hipMalloc(&P, 2 * 80000 * 4)); CK(hipMalloc(&Z2, 2 * B * 256 * 4)); CK(hipMalloc(&Y, 2 * B * 256 * 4));
+  CK(hipMalloc(&DX, 2 * B * 256 * 4)); CK(hipMalloc(&XH, 2 * B * 256 * 4)); CK(hipMalloc(&H, 2 * B * 256 * 4)); CK(hipMalloc(&RS, 2 * B * 4));
+  std::vector<float> hp(2 * 80000); for (size_t i = 0; i < hp.size(); ++i) hp[i] = 0.01f * (float)((i * 2654435761u) % 200) - 1.0f;
+  CK(hipMemcpy(P, hp.data(), hp.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X, hp.data(), B * ldc * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(Z2, hp.data(), 2 * B * 256 * 4, hipMemcpyHostToDevice));
+  const int W1 = 0, b1 = 256 * 16, g1 = b1 + 256, be1 = g1 + 256, W2 = be1 + 256, b2 = W2 + 65536;
+  for (int nets = 1; nets <= 2; ++nets) {
+    NtArgs h{};
+    h.Wt = P + W2; h.ldw = 256; h.bias = P + b2; h.gamma = P + g1; h.beta = P + be1; h.p_ns = 80000;
+    h.Y = Z2; h.ldy = 256; h.y_ns = B * 256; h.M = B; h.N = 256; h.K = 256;
+    h.X = X; h.ldx = ldc; h.K1 = o + a; h.W1 = P + W1; h.ldw1 = 16; h.b1 = P + b1;
+    h.xh_out = XH; h.h_out = H; h.rstd_out = RS; h.act_ns = B * 256;
+    const dim3 grid((B / 16) * 16, 1, nets);
+    double us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true>), grid, dim3(256), 0, s, h); }, 20, 50);
+    char nm[64]; snprintf(nm, 64, "k_nt<1,fused> nets=%d", nets); show(nm, us, 6);
+    NtArgs h2 = h; h2.A = Y; h2.lda = 256; h2.a_ns = B * 256;
+    us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, false>), grid, dim3(256), 0, s, h2); }, 20, 50);
+    snprintf(nm, 64, "k_nt<1,plain> nets=%d", nets); show(nm, us, 6);
+    NnArgs n{}; n.dY = Z2; n.dy_ns = B * 256; n.Wt = P + W2; n.ldw = 256; n.p_ns = 80000; n.dX = DX; n.ldx = 256; n.dx_ns = B * 256; n.M = B; n.Kout = 256;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_nn, grid, dim3(256), 0, s, n); }, 20, 50);
+    snprintf(nm, 64, "k_nn nets=%d", nets); show(nm, us, 5);
+    TnArgs tn{}; tn.dY = Z2; tn.ldy = 256; tn.dy_ns = B * 256; tn.N = 256; tn.X = H; tn.ldx = 256; tn.x_ns = B * 256; tn.K = 256;
+    tn.dW = DX; tn.ldw = 256; tn.dbias = RS; tn.g_ns = B * 256; tn.M = B;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, tn); }, 20, 50);
+    printf("k_tn nets=%d            %6.2f us/launch\n", nets, us);
+  }
+  return 0;
+}
