@@ -167,34 +167,54 @@ static int launch_nn(sactd3_engine* e, hipStream_t s, const NnArgs& g, int nets)
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_tn(sactd3_engine* e, hipStream_t s, const TnArgs& g, int nets) {
-  const dim3 grid((unsigned)(((g.N + 15) / 16) * ((g.ldw + 15) / 16)), 1, (unsigned)nets);
-  hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, g);
+static int launch_tn(sactd3_engine* e, hipStream_t s, TnArgs& g, int nets) {
+  int tiles = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    g.pr[i].tile0 = tiles;
+    tiles += ((g.pr[i].N + 15) / 16) * ((g.pr[i].ldw + 15) / 16);
+  }
+  hipLaunchKernelGGL(k_tn, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
+static TnProb tn_prob(const float* dY, int ldy, long dy_ns, int N, const float* X, int ldx, long x_ns, int K,
+                      int w_off, int ldw, int b_off) {
+  TnProb q{};
+  q.dY = dY; q.ldy = ldy; q.dy_ns = dy_ns; q.N = N; q.X = X; q.ldx = ldx; q.x_ns = x_ns; q.K = K;
+  q.w_off = w_off; q.ldw = ldw; q.b_off = b_off; q.nfin = 0; q.fin_s_off = -1;
+  return q;
+}
+static void tn_fin(TnProb& q, int slot, int off) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin++] = off; }
 
-// The two hidden layers of one MLP trunk: z2 = relu(LN(x W1^T + b1)) W2^T + b2.  One kernel when the input is
-// narrow (first layer recomputed per column strip), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
-struct TrunkStore { float* xh; float* h; float* rstd; };
-static int enqueue_trunk(sactd3_engine* e, hipStream_t s, const float* x, int ldx, long x_ns, int K, int M,
-                         const float* P, const NetLayout& L, long p_ns, int nets, float* z1, float* z2,
-                         TrunkStore st, int* tick0, int* tick1) {
+// The two hidden layers of MLP trunks: z2 = relu(LN(x W1^T + b1)) W2^T + b2 for up to two groups of nets
+// (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
+// (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
+struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
+struct TrunkTicks { int* tick0; int* tick1; float* adam_out; float lr; };
+static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
+                         int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
   NtArgs h{};
-  h.Wt = P + L.W2; h.ldw = HID; h.bias = P + L.b2; h.gamma = P + L.g1; h.beta = P + L.be1; h.p_ns = p_ns;
-  h.Y = z2; h.ldy = HID; h.y_ns = (long)M * HID; h.M = M; h.N = HID; h.K = HID;
-  h.xh_out = st.xh; h.h_out = st.h; h.rstd_out = st.rstd; h.act_ns = (long)M * HID;
+  h.npg = npg; h.oW = L.W2; h.ldw = HID; h.oBias = L.b2; h.oG = L.g1; h.oBe = L.be1; h.p_ns = p_ns;
+  h.ldy = HID; h.y_ns = (long)M * HID; h.M = M; h.N = HID; h.K = HID; h.act_ns = (long)M * HID;
+  for (int i = 0; i < ngrp; ++i) {
+    h.g[i].P = grp[i].P; h.g[i].Y = grp[i].z2; h.g[i].xh_out = grp[i].xh; h.g[i].h_out = grp[i].h; h.g[i].rstd_out = grp[i].rstd;
+  }
+  const int nets = ngrp * npg;
   if (K <= 64) {
-    h.X = x; h.ldx = ldx; h.x_ns = x_ns; h.K1 = K; h.W1 = P + L.W1; h.ldw1 = L.ld1; h.b1 = P + L.b1;
-    h.tick0 = tick0; h.tick1 = tick1;
+    for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].x;
+    h.ld_in = ldx; h.in_ns = 0; h.K1 = K; h.oW1 = L.W1; h.ldw1 = L.ld1; h.oB1 = L.b1;
+    h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
     return launch_nt(e, s, pro, true, h, nets);
   }
   NtArgs g{};
-  g.A = x; g.lda = ldx; g.a_ns = x_ns; g.Wt = P + L.W1; g.ldw = L.ld1; g.bias = P + L.b1; g.p_ns = p_ns;
-  g.Y = z1; g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K; g.tick0 = tick0; g.tick1 = tick1;
+  g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
+  g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
+  for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
+  g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
   RCCHK(launch_nt(e, s, 0, false, g, nets));
-  h.A = z1; h.lda = HID; h.a_ns = (long)M * HID;
+  for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
+  h.ld_in = HID; h.in_ns = (long)M * HID;
   return launch_nt(e, s, pro, false, h, nets);
 }
 
@@ -246,20 +266,21 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
-  const TrunkStore none{nullptr, nullptr, nullptr};
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
-  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o, B, Pact, e->La, 0, 1, e->a_z1, e->a_z2, none,
-                      &e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr));
   {
+    const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g,
+                        TrunkTicks{&e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, c.qnets_lr}));
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
     RCCHK(launch_tail(e, s, t));
   }
-  // twin target critics on (s', a') and twin online critics on (s, a)  (agent.py:208-210, 230-232)
-  RCCHK(enqueue_trunk(e, s, e->Xn, e->ldc, 0, e->o + e->a, B, e->Tc, e->Lc, e->Lc.size, 2, e->t_z1, e->t_z2, none, nullptr, nullptr));
-  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, 2, e->c_z1, e->c_z2,
-                      TrunkStore{e->c_xh1, e->c_h1, e->c_rs1}, nullptr, nullptr));
+  {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232)
+    const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
+                           {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+  }
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
@@ -268,16 +289,6 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.nblk = e->nblk;
     hipLaunchKernelGGL(k_critic_tail, dim3(e->nblk, 2), dim3(256), 0, s, t);
     HIPCHK(hipGetLastError());
-  }
-  {  // dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead
-    TnArgs g{};
-    g.dY = e->c_dz2; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->c_h1; g.ldx = HID; g.x_ns = BH; g.K = HID;
-    g.dW = e->Gc + e->Lc.W2; g.ldw = HID; g.dbias = e->Gc + e->Lc.b2; g.g_ns = e->Lc.size; g.M = B;
-    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
-    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Gc + e->Lc.g2; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Gc + e->Lc.be2; }
-    g.fin_slot[g.nfin] = 2; g.fin_dst[g.nfin++] = e->Gc + e->Lc.Wh;
-    g.part_s = e->part_s; g.fin_s = e->Gc + e->Lc.bh;
-    RCCHK(launch_tn(e, s, g, 2));
   }
   {  // dh1 = dz2 W2
     NnArgs g{};
@@ -293,21 +304,21 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 2), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
-  {  // dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
+  {  // every critic gradient + the Adam step (+ Polyak) in one launch:
+     //   dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead ; dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
     TnArgs g{};
-    g.dY = e->c_dz1; g.ldy = HID; g.dy_ns = BH; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.x_ns = 0; g.K = e->o + e->a;
-    g.dW = e->Gc + e->Lc.W1; g.ldw = e->Lc.ld1; g.dbias = e->Gc + e->Lc.b1; g.g_ns = e->Lc.size; g.M = B;
-    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
-    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Gc + e->Lc.g1; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Gc + e->Lc.be1; }
+    g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
+    g.pr[0] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
+    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2); tn_fin(g.pr[0], 1, e->Lc.be2); }
+    tn_fin(g.pr[0], 2, e->Lc.Wh); g.pr[0].fin_s_off = e->Lc.bh;
+    g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, e->X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
+    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1); tn_fin(g.pr[1], 4, e->Lc.be1); }
+    g.part = e->part; g.nblk = e->nblk; g.part_s = e->part_s;
+    g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
+    g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
+    g.loss_part = e->part_s; g.loss_n = 2 * e->nblk; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
+    g.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS]; g.tick = &e->ctl->noise_ctr;
     RCCHK(launch_tn(e, s, g, 2));
-  }
-  {
-    AdamArgs a = adam_args(e, e->Pc, e->Gc, e->Mc, e->Vc, 2L * e->Lc.size, &e->ctl->t_q, c.qnets_lr);
-    a.loss_part = e->part_s; a.loss_n = 2 * e->nblk; a.loss_stride = 2; a.loss_off = 1; a.loss_scale = 1.0f / (float)B;
-    a.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS];
-    a.tick = &e->ctl->noise_ctr;
-    a.targ = fused_polyak_targ; a.tau = c.polyak;
-    RCCHK(launch_adam(e, s, a));
   }
   return 0;
 }
@@ -318,18 +329,18 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
-  const TrunkStore none{nullptr, nullptr, nullptr};
-  // a_pi, logp = pi(s) with stores for the backward pass
-  RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2,
-                      TrunkStore{e->a_xh1, e->a_h1, e->a_rs1}, &e->ctl->t_a, nullptr));
-  {
+  const bool clip = c.clip_norm > 0.f;
+  {  // a_pi, logp = pi(s) with stores for the backward pass
+    const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, c.actor_lr}));
     ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
     t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
     RCCHK(launch_tail(e, s, t));
   }
-  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
-  RCCHK(enqueue_trunk(e, s, e->Xp, e->ldc, 0, e->o + e->a, B, e->Pc, e->Lc, e->Lc.size, nq, e->c_z1, e->c_z2,
-                      TrunkStore{e->c_xh1, e->c_h1, e->c_rs1}, nullptr, nullptr));
+  {  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
+    const TrunkGrp g{e->Xp, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1};
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+  }
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
@@ -366,20 +377,6 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     hipLaunchKernelGGL(k_actor_head_bwd, dim3(e->nblk), dim3(256), 0, s, h);
     HIPCHK(hipGetLastError());
   }
-  {  // head: dWh = du^T h2, dbh
-    TnArgs g{};
-    g.dY = e->a_du; g.ldy = e->ldu; g.N = e->nh; g.X = e->a_h2; g.ldx = HID; g.K = HID;
-    g.dW = e->Ga + e->La.Wh; g.ldw = HID; g.dbias = e->Ga + e->La.bh; g.M = B;
-    RCCHK(launch_tn(e, s, g, 1));
-  }
-  {
-    TnArgs g{};
-    g.dY = e->a_dz2; g.ldy = HID; g.N = HID; g.X = e->a_h1; g.ldx = HID; g.K = HID;
-    g.dW = e->Ga + e->La.W2; g.ldw = HID; g.dbias = e->Ga + e->La.b2; g.M = B;
-    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
-    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Ga + e->La.g2; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Ga + e->La.be2; }
-    RCCHK(launch_tn(e, s, g, 1));
-  }
   {
     NnArgs g{};
     g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
@@ -392,30 +389,35 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 1), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
-  {
+  {  // every actor gradient (+ Adam unless clip_grad_norm_ needs the global norm first) in one launch:
+     //   dWhead = du^T h2, dbhead ; dW2 = dz2^T h1, db2, dgamma2, dbeta2 ; dW1 = dz1^T s, db1, dgamma1, dbeta1
     TnArgs g{};
-    g.dY = e->a_dz1; g.ldy = HID; g.N = HID; g.X = e->X; g.ldx = e->ldc; g.K = e->o;
-    g.dW = e->Ga + e->La.W1; g.ldw = e->La.ld1; g.dbias = e->Ga + e->La.b1; g.M = B;
-    g.part = e->part; g.nblk = e->nblk; g.nfin = 0;
-    if (ln) { g.fin_slot[g.nfin] = 0; g.fin_dst[g.nfin++] = e->Ga + e->La.g1; g.fin_slot[g.nfin] = 1; g.fin_dst[g.nfin++] = e->Ga + e->La.be1; }
+    g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
+    g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
+    g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
+    if (ln) { tn_fin(g.pr[1], 0, e->La.g2); tn_fin(g.pr[1], 1, e->La.be2); }
+    g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, e->X, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
+    if (ln) { tn_fin(g.pr[2], 3, e->La.g1); tn_fin(g.pr[2], 4, e->La.be1); }
+    g.part = e->part; g.nblk = e->nblk; g.part_s = e->part_s;
+    g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = nullptr; g.adam = e->ctl->adam_a;
+    g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
+    g.loss_part = e->part_s; g.loss_n = e->nblk; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
+    g.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS]; g.tick = (td3 && !clip) ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_tn(e, s, g, 1));
   }
-  if (c.clip_norm > 0.f) {
+  if (clip) {
     NormArgs n{e->Ga, (long)e->La.size, c.clip_norm, e->gscale};
     hipLaunchKernelGGL(k_gradnorm, dim3(1), dim3(1024), 0, s, n);
     HIPCHK(hipGetLastError());
-  }
-  {
     AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, &e->ctl->t_a, c.actor_lr);
-    a.gscale = c.clip_norm > 0.f ? e->gscale : nullptr;
-    a.loss_part = e->part_s; a.loss_n = e->nblk; a.loss_stride = 2; a.loss_off = 1; a.loss_scale = 1.0f / (float)B;
-    a.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS];
+    a.gscale = e->gscale;
     a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_adam(e, s, a));
   }
   if (!td3) {
     if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
-      RCCHK(enqueue_trunk(e, s, e->X, e->ldc, 0, e->o, B, e->Pa, e->La, 0, 1, e->a_z1, e->a_z2, none, nullptr, nullptr));
+      const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
       RCCHK(launch_tail(e, s, t));
     }
@@ -907,7 +909,10 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
     memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
   }
   HIPCHK(hipMemcpyAsync(e->p_x, e->h_obs, sizeof(float) * (size_t)n * e->ldo, hipMemcpyHostToDevice, e->stream));
-  RCCHK(enqueue_trunk(e, e->stream, e->p_x, e->ldo, 0, e->o, n, e->Pa, e->La, 0, 1, e->p_z1, e->p_z2, TrunkStore{nullptr, nullptr, nullptr}, nullptr, nullptr));
+  {
+    const TrunkGrp g{e->p_x, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
+    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+  }
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
   ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr);
   RCCHK(launch_tail(e, e->stream, t));

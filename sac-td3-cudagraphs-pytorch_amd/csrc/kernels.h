@@ -25,7 +25,7 @@
 
 #define HID 256
 #define LN_EPS 1e-5f
-#define NSLOT 4            // column-partial slots per row block: 0 dgamma, 1 dbeta, 2 dWhead (critic)
+#define NSLOT 5            // column-partial slots per row block: 0 dgamma2, 1 dbeta2, 2 dWhead (critic), 3 dgamma1, 4 dbeta1
 #define AS 260             // LDS row stride (floats) of 256-wide row tiles: 16-byte aligned, odd in float4 units
 #define WS 68              // LDS row stride of 64-wide strips read with ds_read_b32 (WS mod 8 == 4: conflict-free)
 #define YS 20              // LDS row stride of 16-wide tiles read with ds_read_b32
@@ -51,6 +51,7 @@ struct DevCtl {
   int inject_eps[8];
   int pad_;
   float metrics[8];
+  float adam_q[2], adam_a[2];   // (lr / (1 - b1^t), sqrt(1 - b2^t)) of the critics' / actor's current step
 };
 
 struct NetLayout {   // float offsets inside one net's parameter block (all multiples of 4)
@@ -251,17 +252,22 @@ __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).z, (b).z, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).w, (b).w, acc, 0, 0, 0);
 
+struct NtGrp {               // one group of nets sharing an input and a parameter arena
+  const float* in;                          // input rows: A (plain) or x (FUSE1); net stride in_ns
+  const float* P;                           // parameter arena of the group's first net; net stride p_ns
+  float* Y;                                 // output, net stride y_ns
+  float* xh_out; float* h_out; float* rstd_out;   // optional stores of the prologue rows by the column-tile-0 blocks
+};
 struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = one 16 x 16 output tile, K split over the 4 waves
-  const float* A; int lda; long a_ns;       // !FUSE1: input rows
-  const float* Wt; int ldw; const float* bias; long p_ns;   // W = Wt + net*p_ns, [N][ldw]
-  const float* gamma; const float* beta;    // LN affine applied to the A rows (PRO == 1)
-  float* Y; int ldy; long y_ns;
+  NtGrp g[2]; int npg;                      // blockIdx.z = grp * npg + net-in-group
+  int ld_in; long in_ns;
+  int oW, ldw, oBias, oG, oBe; long p_ns;   // offsets inside a net's parameter block: W [N][ldw], bias (-1: none), LN affine of the A rows
+  int ldy; long y_ns;
   int M, N, K;                              // PRO != 0 or FUSE1: K == 256
-  // FUSE1: A rows = x W1^T + b1 computed here (x: [M][ldx], K1 <= 64)
-  const float* X; int ldx; long x_ns; int K1; const float* W1; int ldw1; const float* b1;
-  // optional stores of the prologue's rows by the column-tile-0 blocks (all [M][256] / [M], net stride act_ns / M)
-  float* xh_out; float* h_out; float* rstd_out; long act_ns;
+  int K1, oW1, ldw1, oB1;                   // FUSE1: A rows = x W1^T + b1 computed here (x: [M][ld_in], K1 <= 64)
+  long act_ns;                              // net stride of xh_out / h_out ([M][256]); rstd_out is [nets][M]
   int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
+  float* adam_out; float lr, b1, b2;        // with tick0: publish this step's Adam scalars (t = new *tick0)
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -287,45 +293,58 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) *p.tick0 += 1;
+    if (p.tick0) {
+      const int ts = *p.tick0 + 1;
+      *p.tick0 = ts;
+      if (p.adam_out) {
+        p.adam_out[0] = (float)((double)p.lr / (1.0 - pow((double)p.b1, (double)ts)));
+        p.adam_out[1] = (float)sqrt(1.0 - pow((double)p.b2, (double)ts));
+      }
+    }
     if (p.tick1) *p.tick1 += 1;
   }
+  const int grp = net / p.npg, ni = net - grp * p.npg;
+  const NtGrp G = p.g[grp];
+  const float* Pn = G.P + ni * p.p_ns;
   const int tiles_n = (p.N + 15) >> 4;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * 16, n0 = tn * 16;
   const int mrow = min(m0 + r, p.M - 1), nrow = min(n0 + r, p.N - 1);
-  const float* Wrow = p.Wt + net * p.p_ns + (long)nrow * p.ldw;
+  const float* Wrow = Pn + p.oW + (long)nrow * p.ldw;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   if (PRO != 0 || FUSE1) {                 // K == 256: wave w owns k in [64 w, 64 w + 64)
     const int kb = 64 * wave + 4 * kq;
     float4 wv[4], av[4], gv[4], bv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) wv[c] = ld4(Wrow + kb + 16 * c);
-    if (PRO == 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { gv[c] = ld4(p.gamma + net * p.p_ns + kb + 16 * c); bv[c] = ld4(p.beta + net * p.p_ns + kb + 16 * c); }
-    }
-    if (!FUSE1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) av[c] = ld4(p.A + net * p.a_ns + (long)mrow * p.lda + kb + 16 * c);
-    } else {
+    float4 xv[4], w1[4][4], b1v[4];
+    const int C1 = FUSE1 ? (p.K1 + 15) >> 4 : 0;     // <= 4
+    if (FUSE1) {
       // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
-      // z1[m][64 w + 16 c + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer
-      const int C1 = (p.K1 + 15) >> 4;     // <= 4
-      float4 xv[4], w1[4][4], b1v[4];
+      // z1[m][64 w + 16 c + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer.
+      // Its operands are requested first (loads return in order) so that it overlaps the rest of the fetch.
 #pragma unroll
       for (int c1 = 0; c1 < 4; ++c1) {
         const int k = 16 * c1 + 4 * kq;
         const bool on = c1 < C1 && k < p.K1;
-        xv[c1] = on ? zero_beyond(ld4(p.X + net * p.x_ns + (long)mrow * p.ldx + k), k, p.K1) : f4(0.f);
+        xv[c1] = on ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          w1[c][c1] = on ? zero_beyond(ld4(p.W1 + net * p.p_ns + (long)(64 * wave + 16 * c + r) * p.ldw1 + k), k, p.K1) : f4(0.f);
+          w1[c][c1] = on ? zero_beyond(ld4(Pn + p.oW1 + (long)(64 * wave + 16 * c + r) * p.ldw1 + k), k, p.K1) : f4(0.f);
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b1v[c] = ld4(p.b1 + net * p.p_ns + kb + 16 * c);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int c = 0; c < 4; ++c) b1v[c] = ld4(Pn + p.oB1 + kb + 16 * c);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) av[c] = ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + kb + 16 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wv[c] = ld4(Wrow + kb + 16 * c);
+    if (PRO == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { gv[c] = ld4(Pn + p.oG + kb + 16 * c); bv[c] = ld4(Pn + p.oBe + kb + 16 * c); }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // every load above is issued before anything below is scheduled
+    if (FUSE1) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -335,7 +354,6 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
         av[c] = make_float4(z[0] + b1v[c].x, z[1] + b1v[c].y, z[2] + b1v[c].z, z[3] + b1v[c].w);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);     // keep every load above issued before anything below is scheduled
     STAMP(1);
     float4 xh[4];
     float rstd = 1.f;
@@ -373,21 +391,21 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     }
     STAMP(2);
     if (tn == 0 && m0 + r < p.M) {
-      const long ro = net * p.act_ns + (long)(m0 + r) * HID + kb;
-      if (p.xh_out) {
+      const long ro = ni * p.act_ns + (long)(m0 + r) * HID + kb;
+      if (G.xh_out) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) st4(p.xh_out + ro + 16 * c, xh[c]);
+        for (int c = 0; c < 4; ++c) st4(G.xh_out + ro + 16 * c, xh[c]);
       }
-      if (p.h_out) {
+      if (G.h_out) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) st4(p.h_out + ro + 16 * c, av[c]);
+        for (int c = 0; c < 4; ++c) st4(G.h_out + ro + 16 * c, av[c]);
       }
-      if (p.rstd_out && wave == 0 && kq == 0) p.rstd_out[(long)net * p.M + m0 + r] = rstd;
+      if (G.rstd_out && wave == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) { MFMA4(acc, av[c], wv[c]); }
   } else {                                   // generic K (an unfused first layer): wave w takes k chunks w, w+4, ...
-    const float* Arow = p.A + net * p.a_ns + (long)mrow * p.lda;
+    const float* Arow = G.in + ni * p.in_ns + (long)mrow * p.ld_in;
     const int chunks = (p.K + 15) >> 4;
     for (int cb = 0; cb < chunks; cb += 32) {
       float4 a[8], w[8];
@@ -409,8 +427,8 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   STAMP(4);
   const int col = n0 + (lane & 15);
   if (wave == 0 && col < p.N) {
-    const float bias = p.bias ? p.bias[net * p.p_ns + col] : 0.f;
-    float* y = p.Y + net * p.y_ns;
+    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
+    float* y = G.Y + ni * p.y_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 4 * (lane >> 4) + i;
@@ -466,29 +484,73 @@ __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
   STAMP(4);
 }
 
-struct TnArgs {              // dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 written as 0); block = one 16 x 16 tile, m split over waves
+struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 are 0)
   const float* dY; int ldy; long dy_ns; int N;
   const float* X; int ldx; long x_ns; int K;
-  float* dW; int ldw;
-  float* dbias;                          // optional: dbias[n] = sum_m dY[m][n]
-  long g_ns;                             // net stride of every gradient pointer
-  int M;
-  // column partials from a row kernel: part[net][blk][NSLOT][HID] -> fin_dst[e][n] = sum_blk part[..][fin_slot[e]][n]
-  const float* part; int nblk; int nfin; int fin_slot[3]; float* fin_dst[3];
-  const float* part_s; float* fin_s;     // optional scalar: fin_s[0] = sum_blk part_s[net][blk][0]
+  int w_off, ldw;                        // where the weight block sits inside a net's parameter / gradient block
+  int b_off;                             // its bias (gradient = column sums of dY), -1: none
+  int nfin; int fin_slot[3]; int fin_off[3];   // vectors that come from row-kernel partials: part[net][blk][slot][n] summed over blk
+  int fin_s_off;                         // scalar from part_s[net][blk][0] summed over blk (critic head bias), -1: none
+  int tile0;                             // first blockIdx.x of this problem
 };
+struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
+  TnProb pr[3]; int nprob; int M;
+  float* G; long g_ns;                   // gradient arena (always written; net stride g_ns)
+  // optimiser step fused into the epilogue (torch.optim.Adam, agents/agent.py:236,286), optionally with the Polyak
+  // update of the same element (agents/agent.py:328).  apply == 0: gradients only (clip_grad_norm_ path).
+  int apply; float* P; float* Mo; float* Vo; float* T; float tau;
+  const float* adam;                     // [0] lr / (1 - b1^t), [1] sqrt(1 - b2^t), published by the first kernel of the update
+  float b1, b2, eps;
+  const float* part; int nblk; const float* part_s;
+  // extras done once by block 0 / net 0: loss finalisation and a counter tick
+  const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
+};
+
+struct AdamState { float w, m, v, t; };
+__device__ __forceinline__ AdamState adam_fetch(const TnArgs& p, long off) {
+  AdamState s{0.f, 0.f, 0.f, 0.f};
+  if (p.apply) { s.w = p.P[off]; s.m = p.Mo[off]; s.v = p.Vo[off]; if (p.T) s.t = p.T[off]; }
+  return s;
+}
+__device__ __forceinline__ void adam_commit(const TnArgs& p, long off, float g, AdamState s, float step, float sq2) {
+  p.G[off] = g;
+  if (p.apply) {
+    const float m = s.m + (g - s.m) * (1.0f - p.b1);
+    const float v = s.v * p.b2 + g * g * (1.0f - p.b2);
+    const float w = s.w - step * (m / (sqrtf(v) / sq2 + p.eps));
+    p.Mo[off] = m; p.Vo[off] = v; p.P[off] = w;
+    if (p.T) p.T[off] = s.t + (w - s.t) * p.tau;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
   __shared__ float cred[16 * 17];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  const int tiles_k = (p.ldw + 15) >> 4;
-  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  int pi = 0;
+  if (p.nprob > 1 && (int)blockIdx.x >= p.pr[1].tile0) pi = 1;
+  if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
+  const TnProb q = p.pr[pi];
+  const int local = blockIdx.x - q.tile0;
+  const int tiles_k = (q.ldw + 15) >> 4;
+  const int tn = local / tiles_k, tk = local % tiles_k;
   const int n0 = tn * 16, k0 = tk * 16;
-  const float* Dc = p.dY + net * p.dy_ns + min(n0 + r, p.N - 1);
-  const bool kval = k0 + r < p.K;
-  const float* Xc = p.X + net * p.x_ns + min(k0 + r, p.K - 1);
+  const long nbase = net * p.g_ns;
+  // the epilogue's elements: wave 0, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + j
+  const int ecol = k0 + (lane & 15);
+  AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
+  const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = n0 + 4 * (lane >> 4) + i;
+      st[i] = (row < q.N && ecol < q.ldw) ? adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + ecol) : sv;
+    }
+  }
+  const float* Dc = q.dY + net * q.dy_ns + min(n0 + r, q.N - 1);
+  const bool kval = k0 + r < q.K;
+  const float* Xc = q.X + net * q.x_ns + min(k0 + r, q.K - 1);
   const int chunks = (p.M + 15) >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;
@@ -503,7 +565,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
         const int m = 16 * c + 4 * kq + jj;
         const bool on = c < chunks && m < p.M;
         const int mc = on ? m : 0;
-        const float av = Dc[(long)mc * p.ldy], xv = Xc[(long)mc * p.ldx];
+        const float av = Dc[(long)mc * q.ldy], xv = Xc[(long)mc * q.ldx];
         ap[jj] = on ? av : 0.f;
         bp[jj] = (on && kval) ? xv : 0.f;
       }
@@ -513,48 +575,61 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     for (int u = 0; u < 4; ++u) { asum += sum4(a[u]); MFMA4(acc, a[u], b[u]); }
   }
   acc = splitk_reduce(red, acc, wave, lane);
-  if (tk == 0) {
-    const int col = t & 15, part = t >> 4, n = n0 + col;     // (col, part) == (r, 4 wave + kq)
-    if (p.dbias) {
-      cred[part * 17 + col] = asum;
-      __syncthreads();
-      if (t < 16 && n < p.N) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += cred[i * 17 + t];
-        p.dbias[net * p.g_ns + n] = s;
-      }
-    }
-    for (int e = 0; e < p.nfin; ++e) {       // 16 threads per column, blocks strided over them, all loads independent
-      float s = 0.f;
-      if (n < p.N)
-        for (int blk = part; blk < p.nblk; blk += 16)
-          s += p.part[(((long)net * p.nblk + blk) * NSLOT + p.fin_slot[e]) * HID + n];
-      __syncthreads();
-      cred[part * 17 + col] = s;
-      __syncthreads();
-      if (t < 16 && n < p.N) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += cred[i * 17 + t];
-        p.fin_dst[e][net * p.g_ns + n] = v;
-      }
-    }
-    if (p.fin_s && tn == 0 && wave == 1) {
-      float s = 0.f;
-      for (int blk = lane; blk < p.nblk; blk += 64) s += p.part_s[((long)net * p.nblk + blk) * 2];
-      s = wave_sum(s);
-      if (lane == 0) p.fin_s[net * p.g_ns] = s;
-    }
-  }
-  const int col = k0 + (lane & 15);
-  if (wave == 0 && col < p.ldw) {
-    float* w = p.dW + net * p.g_ns;
+  if (wave == 0 && ecol < q.ldw) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = n0 + 4 * (lane >> 4) + i;
-      if (row < p.N) w[(long)row * p.ldw + col] = (col < p.K) ? acc[i] : 0.f;
+      if (row < q.N) adam_commit(p, nbase + q.w_off + (long)row * q.ldw + ecol, ecol < q.K ? acc[i] : 0.f, st[i], step, sq2);
     }
+  }
+  if (tk == 0) {
+    const int col = t & 15, part = t >> 4, n = n0 + col;     // (col, part) == (r, 4 wave + kq)
+    if (q.b_off >= 0) {
+      const long off = nbase + q.b_off + n;
+      if (t < 16 && n < q.N) sv = adam_fetch(p, off);
+      cred[part * 17 + col] = asum;
+      __syncthreads();
+      if (t < 16 && n < q.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += cred[i * 17 + t];
+        adam_commit(p, off, s, sv, step, sq2);
+      }
+    }
+    for (int e = 0; e < q.nfin; ++e) {       // 16 threads per column, blocks strided over them, all loads independent
+      const long off = nbase + q.fin_off[e] + n;
+      if (t < 16 && n < q.N) sv = adam_fetch(p, off);
+      float s = 0.f;
+      if (n < q.N)
+        for (int blk = part; blk < p.nblk; blk += 16)
+          s += p.part[(((long)net * p.nblk + blk) * NSLOT + q.fin_slot[e]) * HID + n];
+      __syncthreads();
+      cred[part * 17 + col] = s;
+      __syncthreads();
+      if (t < 16 && n < q.N) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += cred[i * 17 + t];
+        adam_commit(p, off, v, sv, step, sq2);
+      }
+    }
+    if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
+      const long off = nbase + q.fin_s_off;
+      if (lane == 0) sv = adam_fetch(p, off);
+      float s = 0.f;
+      for (int blk = lane; blk < p.nblk; blk += 64) s += p.part_s[((long)net * p.nblk + blk) * 2];
+      s = wave_sum(s);
+      if (lane == 0) adam_commit(p, off, s, sv, step, sq2);
+    }
+  }
+  if (blockIdx.x == 0 && net == 0 && wave == 2) {
+    if (p.loss_dst) {
+      float s = 0.f;
+      for (int i = lane; i < p.loss_n; i += 64) s += p.loss_part[(long)i * p.loss_stride + p.loss_off];
+      s = wave_sum(s);
+      if (lane == 0) *p.loss_dst = s * p.loss_scale;
+    }
+    if (lane == 0 && p.tick) *p.tick += 1;
   }
 }
 
@@ -584,6 +659,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   const bool valid = b < p.B;
   const int nh = p.L.nh, T = (nh + 15) >> 4;     // head column tiles (<= 4)
   const float* Wh = p.P + p.L.Wh;
+  STAMP(0);
   // loads first: my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3)
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
   Row16 g, be;
@@ -596,6 +672,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       const int n = tt * 16 + r;
       wf[tt][ci] = (tt < T && n < nh) ? ld4(Wh + (long)n * HID + (4 * wave + ci) * 16 + 4 * kq) : f4(0.f);
     }
+  STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
   Row16 h;
@@ -612,6 +689,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       for (int k = sub; k < p.o; k += 16) p.dst[(long)b * p.ldd + k] = p.obs_src[(long)b * p.lds + k];
   }
   __syncthreads();
+  STAMP(2);
   // head: u[16][nh] = h[16][256] Wh^T, K split over the 4 waves
   {
     f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -629,6 +707,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
         for (int i = 0; i < 4; ++i) Up[(wave * 16 + 4 * kq + i) * 64 + tt * 16 + r] = acc[tt][i];
   }
   __syncthreads();
+  STAMP(3);
   float lp = 0.f;
   for (int j = sub; j < p.a; j += 16) {
     const float* u = Up + row * 64;
@@ -672,10 +751,12 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     }
     if (valid) p.dst[(long)b * p.ldd + p.dst_off + j] = act;
   }
+  STAMP(4);
   if (p.sac && p.logp) {
     lp = row16_sum(lp);
     if (sub == 0 && valid) p.logp[b] = lp;
   }
+  STAMP(5);
 }
 
 struct CriticTail {
@@ -695,6 +776,7 @@ __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
   const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const float* Pn = p.P + net * p.p_ns;
+  STAMP(0);
   // loads first
   const Row16 zt0 = row_ld(p.z2t + (long)bc * HID, sub), zt1 = row_ld(p.z2t + ((long)p.B + bc) * HID, sub);
   const Row16 zo = row_ld(p.z2 + ((long)net * p.B + bc) * HID, sub);
@@ -709,6 +791,7 @@ __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
   const float rw = p.rew[bc], dn = p.done[bc];
   const float alpha = p.sac ? expf(*p.log_alpha) : 0.f;
   const float lpn = p.sac ? p.logp_next[bc] : 0.f;
+  STAMP(1);
   Row16 xh, y, h; float rs;
   ln_fwd(zt0, gt0, bt0, p.ln, xh, y, rs);
 #pragma unroll
@@ -743,6 +826,7 @@ __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
     }
   }
   if (sub == 0) { sc[row][0] = dq; sc[row][1] = err * err; }
+  STAMP(2);
   const long blk = (long)net * p.nblk + blockIdx.x;
   block_colsum(cs, vals, 3, row, sub, p.part + blk * NSLOT * HID);   // (has the barrier that publishes sc)
   if (t < 2) {
@@ -751,6 +835,7 @@ __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
     for (int i = 0; i < 16; ++i) s += sc[i][t];
     p.part_s[blk * 2 + t] = s;
   }
+  STAMP(3);
 }
 
 struct ActorQTail {
@@ -842,7 +927,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
   if (p.want_part) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
-    block_colsum(cs, vals, 2, row, sub, p.part + ((long)net * p.nblk + blockIdx.x) * NSLOT * HID);
+    block_colsum(cs, vals, 2, row, sub, p.part + (((long)net * p.nblk + blockIdx.x) * NSLOT + 3) * HID);   // slots 3, 4
   }
 }
 

@@ -58,5 +58,22 @@ int main() {
     us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, tn); }, 20, 50);
     printf("k_tn nets=%d            %6.2f us/launch\n", nets, us);
   }
+  {
+    NetLayout L{}; L.K = o; L.ld1 = 12; L.nh = 2 * a; L.W1 = 0; L.b1 = b1; L.g1 = g1; L.be1 = be1; L.W2 = W2; L.b2 = b2; L.g2 = b2 + 256; L.be2 = b2 + 512; L.Wh = b2 + 768; L.bh = L.Wh + 6 * 256;
+    DevCtl hc{}; DevCtl* ctl; CK(hipMalloc(&ctl, sizeof(DevCtl))); CK(hipMemcpy(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice));
+    float *eps, *sc, *logp, *tg; CK(hipMalloc(&eps, B * 4 * 4)); CK(hipMalloc(&sc, 64)); CK(hipMalloc(&logp, B * 4)); CK(hipMalloc(&tg, B * 16 * 4));
+    float hs[16] = {1, 1, 1, 1, 0, 0, 0, 0, -1, -1, -1, -1, 1, 1, 1, 1}; CK(hipMemcpy(sc, hs, 64, hipMemcpyHostToDevice));
+    ActorTail t{}; t.z2 = Z2; t.P = P; t.L = L; t.B = B; t.o = o; t.a = a; t.ln = 1; t.sac = 1; t.mode = 0; t.train = 1;
+    t.ctl = ctl; t.ctr = &ctl->noise_ctr; t.site_buf = 1; t.site_code = 16; t.eps = eps; t.scale = sc; t.bias = sc + 4; t.min_ac = sc + 8; t.max_ac = sc + 12;
+    t.dst = X; t.ldd = ldc; t.dst_off = o; t.logp = logp; t.h2 = H; t.xh2 = XH; t.rstd2 = RS; t.tg = tg; t.a4 = 4;
+    double us = graph_us(s, [&] { hipLaunchKernelGGL(k_actor_tail, dim3(B / 16), dim3(256), 0, s, t); }, 20, 50);
+    show("k_actor_tail(train)", us, 6);
+    float *q3, *dz, *part, *ps; CK(hipMalloc(&q3, 8 * B * 4)); CK(hipMalloc(&dz, 2 * B * 256 * 4)); CK(hipMalloc(&part, 2 * 16 * 4 * 256 * 4)); CK(hipMalloc(&ps, 2 * 16 * 2 * 4));
+    NetLayout Lc = L; Lc.nh = 1;
+    CriticTail c{}; c.z2t = Z2; c.z2 = Y; c.PT = P; c.P = P; c.p_ns = 80000; c.L = Lc; c.rew = logp; c.done = logp; c.logp_next = logp; c.log_alpha = sc + 4;
+    c.B = B; c.ln = 1; c.sac = 1; c.bcq = 0; c.gamma = 0.99f; c.qt = q3; c.y = q3 + 2 * B; c.q = q3 + 4 * B; c.dz2 = dz; c.part = part; c.part_s = ps; c.nblk = 16;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_critic_tail, dim3(16, 2), dim3(256), 0, s, c); }, 20, 50);
+    show("k_critic_tail", us, 4);
+  }
   return 0;
 }
