@@ -1,0 +1,43 @@
+"""CPU, world_size 2 over gloo: the seed-parallel launcher's sharding, barrier and timing aggregation (the N > 1
+path of bench.py).  Replicas only: no tensor of the learners ever crosses ranks."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from sac_td3_cudagraphs_pytorch_amd import launcher
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = launcher.init_process_group("gloo")
+    seeds = launcher.shard_seeds(8, world, rank)
+    dist.barrier()
+    total, secs = launcher.aggregate(dist, local_units=1000.0 * len(seeds), local_seconds=1.0 + rank)
+    q.put((rank, seeds, total, secs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_seed_sharding_and_aggregation():
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert out[0][1] == [0, 2, 4, 6] and out[1][1] == [1, 3, 5, 7]          # disjoint, complete
+    for _, _, total, secs in out:
+        assert total == 8000.0 and secs == 2.0                              # sum of units, max of times
+
+
+def test_single_process_is_the_identity():
+    assert launcher.shard_seeds(3, 1, 0, first_seed=5) == [5, 6, 7]
+    assert launcher.aggregate(None, 10.0, 2.0) == (10.0, 2.0)
