@@ -237,13 +237,17 @@ static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
   return 0;
 }
 
+// one float4 chunk per thread while that still fills the chip; GATHER_CPT chunks (loads in flight) per thread beyond
+static unsigned gather_blocks(long chunks) {
+  const long one = (chunks + 255) / 256;
+  return (unsigned)(one <= 4096 ? one : (chunks + 256L * GATHER_CPT - 1) / (256L * GATHER_CPT));
+}
 static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, int identity_len) {
   GatherArgs g{};
   g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
   g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
   g.B = e->B; g.len_override = identity_len;
-  const long threads = (long)e->B * e->rec4;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_gather, dim3(gather_blocks((long)e->B * e->rec4)), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1026,8 +1030,7 @@ int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec
     GatherArgs g{};
     g.ring = (const float4*)e->ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = ix;
     g.X = (float4*)X; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
-    const long threads = (long)batch * e->rec4;
-    const dim3 grid((unsigned)((threads + 255) / 256));
+    const dim3 grid(gather_blocks((long)batch * e->rec4));
     hipEvent_t t0, t1;
     hipEventCreate(&t0); hipEventCreate(&t1);
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, e->stream, g);

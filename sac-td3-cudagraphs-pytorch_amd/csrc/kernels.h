@@ -106,10 +106,11 @@ __device__ __forceinline__ float4 zero_beyond(float4 v, int k, int K) {  // elem
 __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned ctr, unsigned site, unsigned e) {
   const Philox4 r = philox4x32_10(ctr, 0u, SACTD3_STREAM_NOISE + site, e >> 2, (uint32_t)seed, (uint32_t)(seed >> 32));
   const unsigned k = e & 3u;
-  const float u1 = philox_u01(r.v[k & 2u]), u2 = philox_u01(r.v[(k & 2u) + 1u]);
-  const float rad = sqrtf(-2.0f * logf(u1));
-  const float th = 6.283185307179586f * u2;
-  return (k & 1u) ? rad * sinf(th) : rad * cosf(th);
+  // (selects, not r.v[k]: a dynamically indexed array would live in scratch memory)
+  const float u1 = philox_u01((k & 2u) ? r.v[2] : r.v[0]), u2 = philox_u01((k & 2u) ? r.v[3] : r.v[1]);
+  // v_log_f32 / v_sin_f32 / v_cos_f32: the trig units take their argument in revolutions, so sin(2 pi u2) is one instruction
+  const float rad = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(u1));
+  return (k & 1u) ? rad * __builtin_amdgcn_sinf(u2) : rad * __builtin_amdgcn_cosf(u2);
 }
 
 // ---- row-owner layout: thread (row = t >> 4, sub = t & 15) holds v[q] = columns 4*sub + 64*q .. +3, q = 0..3
@@ -180,27 +181,35 @@ struct GatherArgs {
   int B; int len_override;                // len_override >= 0: use it instead of ctl->rb_len (staged batches)
 };
 
+#define GATHER_CPT 4    // float4 chunks per thread: loads in flight per lane
 __global__ __launch_bounds__(256) void k_gather(GatherArgs p) {
-  const long g = (long)blockIdx.x * 256 + threadIdx.x;
-  const int b = (int)(g / p.rec4), c = (int)(g % p.rec4);
-  if (b >= p.B) return;
-  int id;
-  if (p.ctl->inject_idx) {
-    id = p.idx[b];
-  } else {
-    const int len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
-    id = (int)philox_index(p.ctl->seed, (unsigned)p.ctl->sample_ctr, (unsigned)b, (unsigned)len);
-    if (c == 0) p.idx[b] = id;
+  const int inject = p.ctl->inject_idx;
+  const unsigned long long seed = p.ctl->seed;
+  const int ctr = p.ctl->sample_ctr, len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
+  const long g0 = ((long)blockIdx.x * 256 + threadIdx.x);
+  const long total = (long)p.B * p.rec4, stride = (long)gridDim.x * 256;
+  int bb[GATHER_CPT], cc[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT];
+#pragma unroll
+  for (int u = 0; u < GATHER_CPT; ++u) {            // consecutive threads -> consecutive chunks of a record
+    const long g = g0 + u * stride;
+    on[u] = g < total;
+    bb[u] = on[u] ? (int)(g / p.rec4) : 0; cc[u] = on[u] ? (int)(g % p.rec4) : 0;
+    int id;
+    if (inject) id = p.idx[bb[u]];
+    else {
+      id = on[u] ? (int)philox_index(seed, (unsigned)ctr, (unsigned)bb[u], (unsigned)len) : 0;
+      if (on[u] && cc[u] == 0) p.idx[bb[u]] = id;
+    }
+    on[u] = on[u] && cc[u] <= p.cx + p.cn;           // trailing pad chunk(s) are not moved
+    v[u] = on[u] ? p.ring[(long)id * p.rec4 + cc[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (c > p.cx + p.cn) return;            // trailing pad chunk(s)
-  const float4 v = p.ring[(long)id * p.rec4 + c];
-  if (c < p.cx) {
-    p.X[(long)b * p.cx + c] = v;
-  } else if (c < p.cx + p.cn) {
-    p.Xn[(long)b * p.cx + (c - p.cx)] = v;
-  } else {
-    p.rew[b] = v.x;
-    p.done[b] = v.y;
+#pragma unroll
+  for (int u = 0; u < GATHER_CPT; ++u) {
+    if (!on[u]) continue;
+    const int b = bb[u], c = cc[u];
+    if (c < p.cx) p.X[(long)b * p.cx + c] = v[u];
+    else if (c < p.cx + p.cn) p.Xn[(long)b * p.cx + (c - p.cx)] = v[u];
+    else { p.rew[b] = v[u].x; p.done[b] = v[u].y; }
   }
 }
 
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   int pi = 0;
   if (p.nprob > 1 && (int)blockIdx.x >= p.pr[1].tile0) pi = 1;
   if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
-  const TnProb q = p.pr[pi];
+  const TnProb& q = p.pr[pi];    // stays in the kernarg segment (a private copy indexed at run time would be scratch memory)
   const int local = blockIdx.x - q.tile0;
   const int tiles_k = (q.ldw + 15) >> 4;
   const int tn = local / tiles_k, tk = local % tiles_k;
@@ -596,7 +605,9 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
         adam_commit(p, off, s, sv, step, sq2);
       }
     }
-    for (int e = 0; e < q.nfin; ++e) {       // 16 threads per column, blocks strided over them, all loads independent
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {            // 16 threads per column, blocks strided over them, all loads independent
+      if (e >= q.nfin) break;
       const long off = nbase + q.fin_off[e] + n;
       if (t < 16 && n < q.N) sv = adam_fetch(p, off);
       float s = 0.f;
@@ -650,6 +661,15 @@ struct ActorTail {
   float td3_std, td3_c, noise_std;
 };
 
+// the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
+__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int bc, int b, int j, bool valid) {
+  if (!need_eps) return 0.f;
+  if (p.ctl->inject_eps[p.site_buf]) return p.eps[(long)bc * p.a + j];
+  const float e = philox_normal(p.ctl->seed, (unsigned)*p.ctr, p.site_code, (unsigned)(bc * p.a + j));
+  if (valid) p.eps[(long)b * p.a + j] = e;
+  return e;
+}
+
 __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   __shared__ __attribute__((aligned(16))) float Hs[16 * AS];
   __shared__ float Up[4 * 16 * 64];
@@ -672,6 +692,12 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       const int n = tt * 16 + r;
       wf[tt][ci] = (tt < T && n < nh) ? ld4(Wh + (long)n * HID + (4 * wave + ci) * 16 + 4 * kq) : f4(0.f);
     }
+  // operands of this thread's first output element (j = sub) and its noise draw: requested / computed up front
+  const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
+  const int j0 = min(sub, p.a - 1);
+  const float e_bh0 = p.P[p.L.bh + j0], e_bh1 = p.sac ? p.P[p.L.bh + p.a + j0] : 0.f;
+  const float e_sc = p.scale[j0], e_bi = p.bias[j0];
+  const float e_eps = sub < p.a ? tail_noise(p, need_eps, bc, b, j0, valid) : 0.f;
   STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
@@ -710,19 +736,15 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   STAMP(3);
   float lp = 0.f;
   for (int j = sub; j < p.a; j += 16) {
+    const bool first = j == sub;
     const float* u = Up + row * 64;
-    const float u0 = ((u[j] + u[1024 + j]) + (u[2048 + j] + u[3072 + j])) + p.P[p.L.bh + j];
-    float e = 0.f;
-    const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
-    if (need_eps) {
-      if (p.ctl->inject_eps[p.site_buf]) e = p.eps[(long)bc * p.a + j];
-      else { e = philox_normal(p.ctl->seed, (unsigned)*p.ctr, p.site_code, (unsigned)(bc * p.a + j)); if (valid) p.eps[(long)b * p.a + j] = e; }
-    }
-    const float sc = p.scale[j], bi = p.bias[j];
+    const float u0 = ((u[j] + u[1024 + j]) + (u[2048 + j] + u[3072 + j])) + (first ? e_bh0 : p.P[p.L.bh + j]);
+    const float e = first ? e_eps : tail_noise(p, need_eps, bc, b, j, valid);
+    const float sc = first ? e_sc : p.scale[j], bi = first ? e_bi : p.bias[j];
     float act;
     if (p.sac) {
       const int j1 = p.a + j;
-      const float u1 = ((u[j1] + u[1024 + j1]) + (u[2048 + j1] + u[3072 + j1])) + p.P[p.L.bh + j1];
+      const float u1 = ((u[j1] + u[1024 + j1]) + (u[2048 + j1] + u[3072 + j1])) + (first ? e_bh1 : p.P[p.L.bh + j1]);
       const float tt = tanhf(u1);
       const float log_std = -5.0f + 3.5f * (tt + 1.0f);
       const float sd = expf(log_std);

@@ -38,7 +38,9 @@ SACTD3_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
 // uniform index in [0, len): Lemire multiply-shift on one 32-bit word (bias <= len / 2^32)
 SACTD3_HD uint32_t philox_index(uint64_t seed, uint32_t ctr, uint32_t b, uint32_t len) {
   const Philox4 r = philox4x32_10(ctr, 0u, SACTD3_STREAM_INDEX, b >> 2, (uint32_t)seed, (uint32_t)(seed >> 32));
-  return (uint32_t)(((uint64_t)r.v[b & 3u] * (uint64_t)len) >> 32);
+  const uint32_t k = b & 3u;   // selects: a dynamically indexed r.v[] would be placed in scratch memory on the GPU
+  const uint32_t w = k == 0 ? r.v[0] : (k == 1 ? r.v[1] : (k == 2 ? r.v[2] : r.v[3]));
+  return (uint32_t)(((uint64_t)w * (uint64_t)len) >> 32);
 }
 
 SACTD3_HD float philox_u01(uint32_t x) {  // (0,1), 24 random bits

@@ -63,3 +63,16 @@ def test_product_package_does_not_import_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert not bad.search(open(os.path.join(dirpath, f)).read()), f
+
+
+def test_no_kernel_spills_to_scratch():
+    """Scratch (private) memory costs a global-memory round trip per access; a dynamically indexed local array is
+    enough to trigger it.  Every kernel must report ScratchSize 0 in hipcc's resource-usage remarks."""
+    import subprocess
+    csrc = os.path.join(ROOT, "sac-td3-cudagraphs-pytorch_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "asm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    names = re.findall(r"Function Name: (\S+)", out)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
+    assert len(names) == len(scratch) and len(names) >= 15, out[-2000:]
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, bad

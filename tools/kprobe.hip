@@ -38,26 +38,6 @@ int main() {
   CK(hipMemcpy(P, hp.data(), hp.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X, hp.data(), B * ldc * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Z2, hp.data(), 2 * B * 256 * 4, hipMemcpyHostToDevice));
   const int W1 = 0, b1 = 256 * 16, g1 = b1 + 256, be1 = g1 + 256, W2 = be1 + 256, b2 = W2 + 65536;
-  for (int nets = 1; nets <= 2; ++nets) {
-    NtArgs h{};
-    h.Wt = P + W2; h.ldw = 256; h.bias = P + b2; h.gamma = P + g1; h.beta = P + be1; h.p_ns = 80000;
-    h.Y = Z2; h.ldy = 256; h.y_ns = B * 256; h.M = B; h.N = 256; h.K = 256;
-    h.X = X; h.ldx = ldc; h.K1 = o + a; h.W1 = P + W1; h.ldw1 = 16; h.b1 = P + b1;
-    h.xh_out = XH; h.h_out = H; h.rstd_out = RS; h.act_ns = B * 256;
-    const dim3 grid((B / 16) * 16, 1, nets);
-    double us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true>), grid, dim3(256), 0, s, h); }, 20, 50);
-    char nm[64]; snprintf(nm, 64, "k_nt<1,fused> nets=%d", nets); show(nm, us, 6);
-    NtArgs h2 = h; h2.A = Y; h2.lda = 256; h2.a_ns = B * 256;
-    us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, false>), grid, dim3(256), 0, s, h2); }, 20, 50);
-    snprintf(nm, 64, "k_nt<1,plain> nets=%d", nets); show(nm, us, 6);
-    NnArgs n{}; n.dY = Z2; n.dy_ns = B * 256; n.Wt = P + W2; n.ldw = 256; n.p_ns = 80000; n.dX = DX; n.ldx = 256; n.dx_ns = B * 256; n.M = B; n.Kout = 256;
-    us = graph_us(s, [&] { hipLaunchKernelGGL(k_nn, grid, dim3(256), 0, s, n); }, 20, 50);
-    snprintf(nm, 64, "k_nn nets=%d", nets); show(nm, us, 5);
-    TnArgs tn{}; tn.dY = Z2; tn.ldy = 256; tn.dy_ns = B * 256; tn.N = 256; tn.X = H; tn.ldx = 256; tn.x_ns = B * 256; tn.K = 256;
-    tn.dW = DX; tn.ldw = 256; tn.dbias = RS; tn.g_ns = B * 256; tn.M = B;
-    us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, grid, dim3(256), 0, s, tn); }, 20, 50);
-    printf("k_tn nets=%d            %6.2f us/launch\n", nets, us);
-  }
   {
     NetLayout L{}; L.K = o; L.ld1 = 12; L.nh = 2 * a; L.W1 = 0; L.b1 = b1; L.g1 = g1; L.be1 = be1; L.W2 = W2; L.b2 = b2; L.g2 = b2 + 256; L.be2 = b2 + 512; L.Wh = b2 + 768; L.bh = L.Wh + 6 * 256;
     DevCtl hc{}; DevCtl* ctl; CK(hipMalloc(&ctl, sizeof(DevCtl))); CK(hipMemcpy(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice));
