@@ -82,6 +82,7 @@ struct sactd3_engine {
   int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
   int nblk = 0;                // row-kernel blocks (16 rows each) for B rows
   int maxn = 0;                // rows accepted by predict
+  int num_cus = 256;
   int stage_rows = 0;
   NetLayout La{}, Lc{};
 
@@ -148,15 +149,25 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 // ------------------------------------------------------------------------------------------------ launches
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
+template <int PRO, bool F1>
+static void launch_nt_ks(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
+  if (ks == 4) hipLaunchKernelGGL((k_nt<PRO, F1, 4>), grid, dim3(256), 0, s, g);
+  else if (ks == 2) hipLaunchKernelGGL((k_nt<PRO, F1, 2>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((k_nt<PRO, F1, 1>), grid, dim3(256), 0, s, g);
+}
+// pro == 0: the generic-K form (unfused first layer).  Otherwise K == 256 and the block shape (16 / 32 / 64 rows x 16
+// columns) is chosen so that the launch has about one block per CU.
 static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const NtArgs& g, int nets) {
-  const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.N + 15) / 16)), 1, (unsigned)nets);
-  if (fuse1) {
-    if (pro == 1) hipLaunchKernelGGL((k_nt<1, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_nt<2, true>), grid, dim3(256), 0, s, g);
+  const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
+  if (pro == 0) {
+    hipLaunchKernelGGL(k_nt_wide, dim3((unsigned)(tiles_m * tiles_n), 1, (unsigned)nets), dim3(256), 0, s, g);
   } else {
-    if (pro == 0) hipLaunchKernelGGL((k_nt<0, false>), grid, dim3(256), 0, s, g);
-    else if (pro == 1) hipLaunchKernelGGL((k_nt<1, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_nt<2, false>), grid, dim3(256), 0, s, g);
+    const int tiles = tiles_m * tiles_n * nets;
+    const int ks = tiles >= 4 * e->num_cus ? 1 : (tiles >= 2 * e->num_cus ? 2 : 4);
+    const int rb = 64 / ks;
+    const dim3 grid((unsigned)(((g.M + rb - 1) / rb) * tiles_n), 1, (unsigned)nets);
+    if (fuse1) { if (pro == 1) launch_nt_ks<1, true>(s, ks, grid, g); else launch_nt_ks<2, true>(s, ks, grid, g); }
+    else { if (pro == 1) launch_nt_ks<1, false>(s, ks, grid, g); else launch_nt_ks<2, false>(s, ks, grid, g); }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -541,6 +552,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   HIPCHK(hipGetDeviceProperties(&prop, c.device_id));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SACTD3_ALLOW_ANY_ARCH"))
     return e->fail(SACTD3_ENODEV, "device is not gfx950 (this library carries gfx950 code objects only)");
+  e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
   e->o = c.ob_dim; e->a = c.ac_dim; e->B = c.batch_size;

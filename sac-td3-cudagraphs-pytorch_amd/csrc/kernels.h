@@ -293,12 +293,202 @@ __device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 
 }
 
 // PRO: 0 none, 1 LayerNorm+ReLU, 2 ReLU.  FUSE1: the A rows are produced by a fused first layer.
-// No LDS staging: every operand is loaded from global memory straight into its MFMA fragment registers, all loads
-// of a wave issued back to back (each block pulls ~32 KB; the per-CU fetch rate is what bounds these kernels).
-template <int PRO, bool FUSE1>
+// KS: how many waves split K for one 16 x 16 tile.  A block always has 4 waves and one 16-column tile of W:
+//   KS = 4 -> 16 rows per block, KS = 2 -> 32 rows, KS = 1 -> 64 rows (each wave a full-K tile of its own rows).
+// The host picks KS so that a launch has about one block per CU: what a CU can fetch per clock (~13 B coalesced,
+// ~7 B in 64-byte pieces) bounds these kernels, so W tiles (and the whole of W1) are fetched ONCE per block with
+// fully coalesced loads, parked in LDS and shared by the block's waves.
+template <int PRO, bool FUSE1, int KS>
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
+  constexpr int RB = 64 / KS, CW = 16 / KS, NP = 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
+  constexpr int W1S = 68;                                                   // LDS row stride of W1 (K1 <= 64)
+  __shared__ __attribute__((aligned(16))) float W2s[16 * AS];
+  __shared__ __attribute__((aligned(16))) float W1s[FUSE1 ? 256 * W1S : 4];
+  __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
+  __shared__ __attribute__((aligned(16))) float stat[RB * SS];
+  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
+  const int r = lane & 15, kq = lane >> 4;
+  const int mt = wave / KS, ks = wave % KS;
+  if (blockIdx.x == 0 && t == 0 && net == 0) {
+    if (p.tick0) {
+      const int ts = *p.tick0 + 1;
+      *p.tick0 = ts;
+      if (p.adam_out) {
+        p.adam_out[0] = (float)((double)p.lr / (1.0 - pow((double)p.b1, (double)ts)));
+        p.adam_out[1] = (float)sqrt(1.0 - pow((double)p.b2, (double)ts));
+      }
+    }
+    if (p.tick1) *p.tick1 += 1;
+  }
+  const int grp = net / p.npg, ni = net - grp * p.npg;
+  const NtGrp G = p.g[grp];
+  const float* Pn = G.P + ni * p.p_ns;
+  const int tiles_n = (p.N + 15) >> 4;
+  const int tmb = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tmb * RB + 16 * mt, n0 = tn * 16;          // this wave's rows / the block's columns
+  const int mrow = min(m0 + r, p.M - 1);
+  const int kb = (ks * CW) * 16 + 4 * kq;                    // first k of this lane's fragments
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  STAMP(0);
+  // ---- 1. every global load, coalesced where the data is shared by the block
+  float4 w2r[4], w1r[16], vr = f4(0.f), xv[4], av[CW];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {                              // W tile: 16 rows x 256 floats, one row per wave-instruction
+    const int i = t + 256 * u, row = i >> 6, c4 = i & 63, n = min(n0 + row, p.N - 1);
+    w2r[u] = ld4(Pn + p.oW + (long)n * p.ldw + 4 * c4);
+  }
+  const int w1n = FUSE1 ? (HID * p.ldw1) >> 2 : 0;           // float4s of W1 (rows are 16-byte multiples, contiguous)
+  if (FUSE1) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int f = t + 256 * u;
+      w1r[u] = f < w1n ? ld4(Pn + p.oW1 + 4 * (long)f) : f4(0.f);
+    }
+    const int C1 = (p.K1 + 15) >> 4;
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1) {
+      const int k = 16 * c1 + 4 * kq;
+      xv[c1] = (c1 < C1 && k < p.K1) ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) av[c] = ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + kb + 16 * c);
+  }
+  if (t < 192) {                                             // b1 | gamma | beta as one 3 x 256 vector
+    const int which = t >> 6, c4 = t & 63;
+    const int off = which == 0 ? p.oB1 : (which == 1 ? p.oG : p.oBe);
+    if ((which == 0 && FUSE1) || (which != 0 && PRO == 1)) vr = ld4(Pn + off + 4 * c4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 2. park the shared operands in LDS (W1 first: the first layer only needs W1, x, b1)
+  if (FUSE1) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int f = t + 256 * u;
+      if (f < w1n) { const int e = 4 * f, row = e / p.ldw1, col = e - row * p.ldw1; st4(W1s + row * W1S + col, w1r[u]); }
+    }
+  }
+  if (t < 192) st4(vec + 4 * t, vr);
+  __syncthreads();
+  STAMP(1);
+  if (FUSE1) {
+    // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
+    // z1[m][16 (ks CW + c) + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer
+    const int C1 = (p.K1 + 15) >> 4;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int tile = ks * CW + c;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1)
+        if (c1 < C1) {
+          const int k = 16 * c1 + 4 * kq;
+          const float4 wf = k < p.ldw1 ? ld4(W1s + (tile * 16 + r) * W1S + k) : f4(0.f);
+          MFMA4(z, wf, xv[c1]);
+        }
+      const float4 b1 = ld4(vec + tile * 16 + 4 * kq);
+      av[c] = make_float4(z[0] + b1.x, z[1] + b1.y, z[2] + b1.z, z[3] + b1.w);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int i = t + 256 * u; st4(W2s + (i >> 6) * AS + 4 * (i & 63), w2r[u]); }
+  // ---- 3. prologue on the A rows held in registers
+  float4 xh[CW];
+  float rstd = 1.f;
+  if (PRO == 1) {
+    // this lane holds 4 CW of the row's 256 values; combine the NP (mean, M2) partials of the row (Chan et al.)
+    constexpr float nl = 4.0f * CW;
+    float ml = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) ml += sum4(av[c]);
+    ml *= (1.0f / nl);
+    float m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { const float4 d = av[c] - f4(ml); m2 += dot4(d, d); }
+    float* srow = stat + (16 * mt + r) * SS;
+    srow[2 * (ks * 4 + kq)] = ml;
+    srow[2 * (ks * 4 + kq) + 1] = m2;
+    __syncthreads();
+    float4 sp[NP / 2];
+#pragma unroll
+    for (int i = 0; i < NP / 2; ++i) sp[i] = ld4(srow + 4 * i);    // (mean, M2) x 2 per float4
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP / 2; ++i) mean += sp[i].x + sp[i].z;
+    mean *= (1.0f / NP);
+    float M2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP / 2; ++i) {
+      const float d0 = sp[i].x - mean, d1 = sp[i].z - mean;
+      M2 += (sp[i].y + sp[i].w) + nl * (d0 * d0 + d1 * d1);
+    }
+    rstd = 1.0f / sqrtf(M2 * (1.0f / HID) + LN_EPS);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const float4 gv = ld4(vec + HID + kb + 16 * c), bv = ld4(vec + 2 * HID + kb + 16 * c);
+      xh[c] = (av[c] - f4(mean)) * rstd;
+      av[c] = relu4(xh[c] * gv + bv);
+    }
+  } else {
+    __syncthreads();
+    if (PRO == 2) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c) { xh[c] = av[c]; av[c] = relu4(av[c]); }
+    }
+  }
+  STAMP(2);
+  if (PRO != 0 && tn == 0 && m0 + r < p.M) {
+    const long ro = ni * p.act_ns + (long)(m0 + r) * HID + kb;
+    if (G.xh_out) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c) st4(G.xh_out + ro + 16 * c, xh[c]);
+    }
+    if (G.h_out) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c) st4(G.h_out + ro + 16 * c, av[c]);
+    }
+    if (G.rstd_out && ks == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
+  }
+  // ---- 4. second layer: this wave's rows x the block's 16 columns over its K range (W tile from LDS)
+  const float* wrow = W2s + r * AS + kb;
+#pragma unroll
+  for (int c = 0; c < CW; c += 2) {
+    const float4 w0 = ld4(wrow + 16 * c);
+    MFMA4(acc0, av[c], w0);
+    if (c + 1 < CW) { const float4 w1 = ld4(wrow + 16 * c + 16); MFMA4(acc1, av[c + 1], w1); }
+  }
+  f32x4 acc;
+  acc[0] = acc0[0] + acc1[0]; acc[1] = acc0[1] + acc1[1]; acc[2] = acc0[2] + acc1[2]; acc[3] = acc0[3] + acc1[3];
+  STAMP(3);
+  if (KS > 1) {                               // sum the KS K-slices of each 16 x 16 tile; the ks == 0 wave keeps the total
+    st4(red + (wave * 64 + lane) * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+      for (int j = 1; j < KS; ++j) {
+        const float4 o = ld4(red + ((wave + j) * 64 + lane) * 4);
+        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+      }
+    }
+  }
+  STAMP(4);
+  const int col = n0 + (lane & 15);
+  if (ks == 0 && col < p.N) {
+    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
+    float* y = G.Y + ni * p.y_ns;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 4 * (lane >> 4) + i;
+      if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bias;
+    }
+  }
+  STAMP(5);
+}
+
+// Generic-K form (an unfused first layer wider than 64 inputs): 16 x 16 tile per block, wave w takes k chunks w, w+4, ...
+__global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
-  __shared__ __attribute__((aligned(16))) float stat[16 * 36];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
@@ -318,122 +508,24 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int tiles_n = (p.N + 15) >> 4;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * 16, n0 = tn * 16;
-  const int mrow = min(m0 + r, p.M - 1), nrow = min(n0 + r, p.N - 1);
-  const float* Wrow = Pn + p.oW + (long)nrow * p.ldw;
+  const float* Arow = G.in + ni * p.in_ns + (long)min(m0 + r, p.M - 1) * p.ld_in;
+  const float* Wrow = Pn + p.oW + (long)min(n0 + r, p.N - 1) * p.ldw;
+  const int chunks = (p.K + 15) >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  STAMP(0);
-  if (PRO != 0 || FUSE1) {                 // K == 256: wave w owns k in [64 w, 64 w + 64)
-    const int kb = 64 * wave + 4 * kq;
-    float4 wv[4], av[4], gv[4], bv[4];
-    float4 xv[4], w1[4][4], b1v[4];
-    const int C1 = FUSE1 ? (p.K1 + 15) >> 4 : 0;     // <= 4
-    if (FUSE1) {
-      // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
-      // z1[m][64 w + 16 c + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer.
-      // Its operands are requested first (loads return in order) so that it overlaps the rest of the fetch.
+  for (int cb = 0; cb < chunks; cb += 32) {
+    float4 a[8], w[8];
 #pragma unroll
-      for (int c1 = 0; c1 < 4; ++c1) {
-        const int k = 16 * c1 + 4 * kq;
-        const bool on = c1 < C1 && k < p.K1;
-        xv[c1] = on ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          w1[c][c1] = on ? zero_beyond(ld4(Pn + p.oW1 + (long)(64 * wave + 16 * c + r) * p.ldw1 + k), k, p.K1) : f4(0.f);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) b1v[c] = ld4(Pn + p.oB1 + kb + 16 * c);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) av[c] = ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + kb + 16 * c);
+    for (int u = 0; u < 8; ++u) {
+      const int c = cb + wave + 4 * u, k = 16 * c + 4 * kq;
+      const bool on = c < chunks && k < p.K;
+      a[u] = on ? zero_beyond(ld4(Arow + k), k, p.K) : f4(0.f);
+      w[u] = on ? zero_beyond(ld4(Wrow + k), k, p.K) : f4(0.f);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) wv[c] = ld4(Wrow + kb + 16 * c);
-    if (PRO == 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { gv[c] = ld4(Pn + p.oG + kb + 16 * c); bv[c] = ld4(Pn + p.oBe + kb + 16 * c); }
-    }
-    __builtin_amdgcn_sched_barrier(0);     // every load above is issued before anything below is scheduled
-    if (FUSE1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c1 = 0; c1 < 4; ++c1)
-          if (c1 < C1) { MFMA4(z, w1[c][c1], xv[c1]); }
-        av[c] = make_float4(z[0] + b1v[c].x, z[1] + b1v[c].y, z[2] + b1v[c].z, z[3] + b1v[c].w);
-      }
-    }
-    STAMP(1);
-    float4 xh[4];
-    float rstd = 1.f;
-    if (PRO == 1) {
-      // row statistics: this lane holds 16 of the row's 256 values; combine the 16 (mean, M2) partials (Chan et al.)
-      float ml = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) ml += sum4(av[c]);
-      ml *= (1.0f / 16.0f);
-      float m2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { const float4 d = av[c] - f4(ml); m2 += dot4(d, d); }
-      stat[r * 36 + (wave * 4 + kq) * 2] = ml;
-      stat[r * 36 + (wave * 4 + kq) * 2 + 1] = m2;
-      __syncthreads();
-      float4 s[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] = ld4(stat + r * 36 + 4 * i);    // (mean, M2) x 2 per float4
-      float mean = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) mean += s[i].x + s[i].z;
-      mean *= (1.0f / 16.0f);
-      float M2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float d0 = s[i].x - mean, d1 = s[i].z - mean;
-        M2 += (s[i].y + s[i].w) + 16.0f * (d0 * d0 + d1 * d1);
-      }
-      rstd = 1.0f / sqrtf(M2 * (1.0f / HID) + LN_EPS);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { xh[c] = (av[c] - f4(mean)) * rstd; av[c] = relu4(xh[c] * gv[c] + bv[c]); }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { xh[c] = av[c]; av[c] = relu4(av[c]); }
-    }
-    STAMP(2);
-    if (tn == 0 && m0 + r < p.M) {
-      const long ro = ni * p.act_ns + (long)(m0 + r) * HID + kb;
-      if (G.xh_out) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) st4(G.xh_out + ro + 16 * c, xh[c]);
-      }
-      if (G.h_out) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) st4(G.h_out + ro + 16 * c, av[c]);
-      }
-      if (G.rstd_out && wave == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { MFMA4(acc, av[c], wv[c]); }
-  } else {                                   // generic K (an unfused first layer): wave w takes k chunks w, w+4, ...
-    const float* Arow = G.in + ni * p.in_ns + (long)mrow * p.ld_in;
-    const int chunks = (p.K + 15) >> 4;
-    for (int cb = 0; cb < chunks; cb += 32) {
-      float4 a[8], w[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = cb + wave + 4 * u, k = 16 * c + 4 * kq;
-        const bool on = c < chunks && k < p.K;
-        a[u] = on ? zero_beyond(ld4(Arow + k), k, p.K) : f4(0.f);
-        w[u] = on ? zero_beyond(ld4(Wrow + k), k, p.K) : f4(0.f);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { MFMA4(acc, a[u], w[u]); }
-    }
-    STAMP(1); STAMP(2);
+    for (int u = 0; u < 8; ++u) { MFMA4(acc, a[u], w[u]); }
   }
-  STAMP(3);
   acc = splitk_reduce(red, acc, wave, lane);
-  STAMP(4);
   const int col = n0 + (lane & 15);
   if (wave == 0 && col < p.N) {
     const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
@@ -444,7 +536,6 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bias;
     }
   }
-  STAMP(5);
 }
 
 struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout] ; block = one 16 x 16 tile, n split over waves

@@ -38,6 +38,20 @@ int main() {
   CK(hipMemcpy(P, hp.data(), hp.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(X, hp.data(), B * ldc * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Z2, hp.data(), 2 * B * 256 * 4, hipMemcpyHostToDevice));
   const int W1 = 0, b1 = 256 * 16, g1 = b1 + 256, be1 = g1 + 256, W2 = be1 + 256, b2 = W2 + 65536;
+  for (int ks : {4, 2, 1}) {
+    const int nets = ks == 4 ? 1 : (ks == 2 ? 2 : 4);
+    NtArgs h{};
+    h.npg = nets; h.g[0].in = X; h.g[0].P = P; h.g[0].Y = Z2; h.g[0].xh_out = XH; h.g[0].h_out = H; h.g[0].rstd_out = RS;
+    h.ld_in = ldc; h.in_ns = 0; h.oW = W2; h.ldw = 256; h.oBias = b2; h.oG = g1; h.oBe = be1; h.p_ns = 0;
+    h.ldy = 256; h.y_ns = 0; h.M = B; h.N = 256; h.K = 256; h.K1 = o + a; h.oW1 = W1; h.ldw1 = 16; h.oB1 = b1; h.act_ns = 0;
+    const int rb = 64 / ks;
+    const dim3 grid((B / rb) * 16, 1, nets);
+    double us;
+    if (ks == 4) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 4>), grid, dim3(256), 0, s, h); }, 20, 50);
+    else if (ks == 2) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 2>), grid, dim3(256), 0, s, h); }, 20, 50);
+    else us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 1>), grid, dim3(256), 0, s, h); }, 20, 50);
+    char nm[64]; snprintf(nm, 64, "k_nt<1,fused,KS=%d> nets=%d", ks, nets); show(nm, us, 6);
+  }
   {
     NetLayout L{}; L.K = o; L.ld1 = 12; L.nh = 2 * a; L.W1 = 0; L.b1 = b1; L.g1 = g1; L.be1 = be1; L.W2 = W2; L.b2 = b2; L.g2 = b2 + 256; L.be2 = b2 + 512; L.Wh = b2 + 768; L.bh = L.Wh + 6 * 256;
     DevCtl hc{}; DevCtl* ctl; CK(hipMalloc(&ctl, sizeof(DevCtl))); CK(hipMemcpy(ctl, &hc, sizeof(hc), hipMemcpyHostToDevice));
