@@ -48,7 +48,7 @@ def make_engine(w, seed, device_id):
     return eng
 
 
-def oracle_rate(w, device, seconds, threads=None):
+def oracle_rate(w, device, seconds, threads=None, min_iters=0):
     """iterations/s of the plain-torch restatement (oracle) on `device`: the reference's CPU / eager-ROCm path."""
     import torch
     from oracle.sac_td3_ref import Hps, RefAgent
@@ -79,7 +79,7 @@ def oracle_rate(w, device, seconds, threads=None):
         i += 1
         if i % 3 == 0:
             sync()
-            if time.perf_counter() - t0 >= seconds:
+            if time.perf_counter() - t0 >= seconds and i >= min_iters:
                 break
     sync()
     return i / (time.perf_counter() - t0), i
@@ -93,8 +93,21 @@ def main():
     ap.add_argument("--workload", default="hopper_sac", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-baselines", action="store_true")
+    ap.add_argument("--eager-profile", type=int, default=0, metavar="ITERS",
+                    help="run ONLY the eager PyTorch-ROCm restatement for ITERS iterations (for rocprofv3 launch counts)")
+    ap.add_argument("--gather-profile", type=int, default=0, metavar="BATCH",
+                    help="run ONLY the replay gather at this batch size 20 times (for rocprofv3 --pmc traffic counters)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
+    if args.eager_profile:
+        v, n = oracle_rate(w, "cuda", 0.0, min_iters=args.eager_profile)
+        print(json.dumps({"eager_rocm_iterations": n, "rate": v}))
+        return
+    if args.gather_profile:
+        eng = make_engine(w, 0, 0)
+        us, by = eng.time_gather_sweep(args.gather_profile, 20)
+        print(json.dumps({"batch": args.gather_profile, "us": us, "algo_bytes": by, "GB/s": by / us * 1e-3}))
+        return
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
