@@ -160,7 +160,14 @@ def main():
         us = eng.time_kernel("gather", 2000)
         ab = gather_algo_bytes(w["o"], w["a"], w["batch"])
         out["roofline"] = {"kernel": "k_gather", "bound": "hbm", "achieved": ab / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ab / us * 1e-3 / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": ab, "avg_launch_us": us}
+                           "frac": ab / us * 1e-3 / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": ab, "avg_launch_us": us,
+                           "note": "B=256 is launch/latency-bound by construction; see gather_batch_sweep for the bandwidth end "
+                                   "and profiles/r01_gather_humanoid_b65536_pmc.csv for the PMC traffic (1.03x algorithmic)"}
+        # the kernel that takes the most time: hidden layers of the 4 critics (fp32 MFMA); FLOPs = 2*MAC of both layers
+        us_t = eng.time_kernel("trunk_critics", 500)
+        fl = 4 * 2.0 * w["batch"] * 256 * ((w["o"] + w["a"]) + 256)
+        out["roofline_mfma"] = {"kernel": "k_nt (4-net critic trunk)", "bound": "mfma", "achieved": fl / us_t * 1e-6, "peak": 157.3,
+                                "unit": "TFLOP/s", "frac": fl / us_t * 1e-6 / 157.3, "flops_per_launch": fl, "avg_launch_us": us_t}
         if world == 1 and not args.no_baselines:
             # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
             sweep = {}

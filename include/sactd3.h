@@ -171,7 +171,8 @@ const char* sactd3_debug_names(void);
 /* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1) */
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph);
 /* average device time in microseconds of `iters` back-to-back launches of one kernel of the path,
- * measured with hipEvents on the engine's stream: "gather", "polyak", "adam_critics" ... [sync] */
+ * measured with hipEvents on the engine's stream: "gather", "polyak", "trunk_critics" (the 4-net hidden-layer
+ * launch of update_qnets; on wide inputs it is two launches). [sync] */
 int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec);
 /* run the replay gather at an arbitrary batch size (<= max set at create via env SACTD3_SWEEP_MAX_B) */
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes);

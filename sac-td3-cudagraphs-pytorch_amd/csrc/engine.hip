@@ -291,7 +291,9 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
     ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
     RCCHK(launch_tail(e, s, t));
   }
-  {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232)
+  {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232).
+     // (Measured: running the online pair on a fork/join side branch of the graph instead costs +30 us per replay on
+     //  ROCm 7.2 -- cross-stream edges are far dearer than the 1.7 us of a linear edge -- so graphs stay linear.)
     const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
                            {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
@@ -1011,7 +1013,12 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
   auto body = [&]() -> int {
     if (!strcmp(kernel, "gather")) return enqueue_gather(e, e->stream, e->ring, -1);
     if (!strcmp(kernel, "polyak")) return enqueue_polyak(e, e->stream, true, e->cfg.prefer_td3_over_sac);
-    return e->fail(SACTD3_EINVAL, "time_kernel: unknown kernel (gather | polyak)");
+    if (!strcmp(kernel, "trunk_critics")) {   // the 4-net hidden-layer launch of update_qnets (no state is modified)
+      const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
+                             {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
+      return enqueue_trunk(e, e->stream, e->ldc, e->o + e->a, e->B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, 0.f});
+    }
+    return e->fail(SACTD3_EINVAL, "time_kernel: unknown kernel (gather | polyak | trunk_critics)");
   };
   for (int i = 0; i < 3 && rc == 0; ++i) rc = body();   // warm-up
   if (rc == 0) {
