@@ -40,7 +40,8 @@ class CConfig(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libsactd3_hip.so")
+    """In-tree build product; SACTD3_LIBRARY overrides it (A/B-testing kernel variants)."""
+    return os.environ.get("SACTD3_LIBRARY") or os.path.join(_HERE, "libsactd3_hip.so")
 
 
 def build_library(force: bool = False) -> str:

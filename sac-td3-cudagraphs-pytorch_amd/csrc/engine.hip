@@ -376,14 +376,10 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = 0;
     l.dz = e->c_dz1; l.part = e->part; l.nblk = e->nblk;
+    // fused: dA_i = dz1_i W1_i[:, o:o+a]  (gradient of Q_i with respect to the action)
+    l.W1 = e->Pc + e->Lc.W1; l.ldw1 = e->Lc.ld1; l.k_off = e->o; l.na = e->a; l.dA = e->dA; l.ldA = e->a4;
     hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, nq), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
-  }
-  {  // dA_i = dz1_i W1_i[:, o:o+a]
-    NnArgs g{};
-    g.dY = e->c_dz1; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W1; g.ldw = e->Lc.ld1; g.p_ns = e->Lc.size; g.k_off = e->o;
-    g.dX = e->dA; g.ldx = e->a4; g.dx_ns = (long)B * e->a4; g.M = B; g.Kout = e->a;
-    RCCHK(launch_nn(e, s, g, nq));
   }
   {
     ActorHeadBwd h{};

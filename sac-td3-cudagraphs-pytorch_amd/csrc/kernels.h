@@ -1020,11 +1020,15 @@ struct LnBwd {               // dz = LNbwd(relu'(.) * dh) for hidden layer 1; op
   int B, ln, want_part;
   float* dz;
   float* part; int nblk;
+  // optional fused input gradient of a slice of layer 1: dA[net][b][0:na] = dz[b][:] . W1[:, k_off : k_off + na]
+  // (the dQ/da path of the actor update, agents/agent.py:272-283; na <= 32, not combined with want_part)
+  const float* W1; int ldw1, k_off, na; float* dA; int ldA;
 };
 
 __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
   __shared__ __attribute__((aligned(16))) float cs[2 * 16 * HID];
-  const int t = threadIdx.x, row = t >> 4, sub = t & 15, net = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, row = t >> 4, sub = t & 15, net = blockIdx.y;
+  const int r = lane & 15, kq = lane >> 4;
   const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const long ro = ((long)net * p.B + bc) * HID;
@@ -1032,6 +1036,19 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
   Row16 g;
   if (p.ln) g = row_ld(p.gamma + net * p.p_ns, sub);
   const float rstd = p.ln ? p.rstd[(long)net * p.B + bc] : 1.f;
+  // B operand of the fused slice product, requested up front: W1[n = 16 (4 wave + ci) + 4 kq + jj][k_off + 16 tt + r]
+  const int T = p.dA ? (p.na + 15) >> 4 : 0;
+  float4 wf[2][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      wf[tt][ci] = f4(0.f);
+      if (tt < T && 16 * tt + r < p.na) {
+        const float* w = p.W1 + net * p.p_ns + (long)(16 * (4 * wave + ci) + 4 * kq) * p.ldw1 + p.k_off + 16 * tt + r;
+        wf[tt][ci] = make_float4(w[0], w[p.ldw1], w[2 * (long)p.ldw1], w[3 * (long)p.ldw1]);
+      }
+    }
   Row16 dy, vals[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { dy.v[q] = gate4(dh.v[q], hh.v[q]); if (!valid) dy.v[q] = f4(0.f); }
@@ -1041,6 +1058,29 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
     block_colsum(cs, vals, 2, row, sub, p.part + (((long)net * p.nblk + blockIdx.x) * NSLOT + 3) * HID);   // slots 3, 4
+  } else if (p.dA) {
+    float* Dz = cs;                      // [16][AS]
+    float* Up = cs + 16 * AS;            // [4 waves][16 rows][32]
+    row_st(Dz + row * AS, sub, dz);
+    __syncthreads();
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float4 av = ld4(Dz + r * AS + (4 * wave + ci) * 16 + 4 * kq);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        if (tt < T) { MFMA4(acc[tt], av, wf[tt][ci]); }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+      if (tt < T)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Up[(wave * 16 + 4 * kq + i) * 32 + tt * 16 + r] = acc[tt][i];
+    __syncthreads();
+    for (int j = sub; j < p.na; j += 16) {
+      const float* u = Up + row * 32 + j;
+      if (valid) p.dA[((long)net * p.B + b) * p.ldA + j] = (u[0] + u[512]) + (u[1024] + u[1536]);
+    }
   }
 }
 
