@@ -176,9 +176,16 @@ def main():
                 sweep[str(bs)] = {"us": us_b, "GB/s": by / us_b * 1e-3}
             out["gather_batch_sweep"] = sweep
             eng.close()
-            v, n = oracle_rate(w, "cpu", args.cpu_seconds)
-            out["cpu_baseline"] = {"value": v, "unit": "gradient-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"{n} iterations of the same workload through oracle/sac_td3_ref.py (plain PyTorch CPU eager)"}
+            # the op sizes are tiny: torch's default of one thread per host core (128 here) is slower than a few threads,
+            # so time 1 and 8 threads on a bounded sample each and report the faster one
+            best = None
+            for nt in (1, 8):
+                v, n = oracle_rate(w, "cpu", args.cpu_seconds / 2, threads=nt)
+                if best is None or v > best[0]:
+                    best = (v, n, nt)
+            out["cpu_baseline"] = {"value": best[0], "unit": "gradient-steps/s", "cores": best[2], "kind": "port",
+                                   "sample": f"{best[1]} iterations of the same workload through oracle/sac_td3_ref.py "
+                                             f"(plain PyTorch CPU eager, torch.set_num_threads({best[2]}); faster of 1 and 8 threads)"}
             v, n = oracle_rate(w, "cuda", 6.0)
             out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
                                           "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
