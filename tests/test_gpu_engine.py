@@ -419,3 +419,52 @@ def test_agent_mirror_drives_like_the_reference():
     assert set(vals) == {"loss/qf_loss", "loss/actor_loss", "loss/alpha_loss", "vitals/alpha"}
     assert all(np.isfinite(v) for v in vals.values())
     assert batch["observations"].shape == (64, o) and batch["dones"].shape == (64, 1)
+
+
+# ------------------------------------------------------------------------------------------ config corners
+
+@pytest.mark.parametrize("algo,env,B,hp", [
+    ("sac", "hopper", 256, dict(autotune=False)),                       # fixed temperature (agents/agent.py:313-318)
+    ("sac", "hopper", 256, dict(bcq_style_targ_mix=True)),              # soft-min target mix with SAC
+    ("td3", "halfcheetah", 256, dict(targ_actor_smoothing=False)),      # agents/agent.py:201-202
+    ("td3", "halfcheetah", 256, dict(bcq_style_targ_mix=False)),        # hard min (TD3 paper)
+    ("sac", "humanoid", 1024, dict()),                                  # BASELINE config 4 shape (wide first layer, B=1024)
+    ("sac", "hopper", 4096, dict()),                                    # largest batch of the scope (batch <= 4096)
+    ("sac", "hopper", 1, dict()),                                       # degenerate batch
+])
+def test_one_iteration_config_corners(algo, env, B, hp):
+    ref, eng, (o, a, bound) = make_pair(algo, env, B, **hp)
+    obs, act, rew, nobs, done = synth_transitions(B, o, a, bound, seed=31)
+    g = torch.Generator().manual_seed(32)
+    noise = {"critic": torch.randn(B, a, generator=g), "actor": [torch.randn(B, a, generator=g) for _ in range(2)],
+             "alpha": [torch.randn(B, a, generator=g) for _ in range(2)]}
+    want = {k: float(v) for k, v in ref.iteration(ref.to_batch(obs, act, rew, nobs, done), 0, noise).items()}
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.set_noise(_lib.SITE_CRITIC, noise["critic"])
+    eng.update_qnets()
+    for j in range(2):
+        eng.set_noise(_lib.SITE_ACTOR0, noise["actor"][j]); eng.set_noise(_lib.SITE_ALPHA0, noise["alpha"][j])
+        eng.update_actor()
+    eng.update_targ_nets(1)
+    got = eng.read_metrics()
+    for k, v in want.items():
+        np.testing.assert_allclose(got[k], v, rtol=2e-5, atol=2e-5, err_msg=k)
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics")
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=1e-2)
+    close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), rtol=1e-5, atol=1e-5, name="targets")
+    if algo == "td3":
+        close(eng.get_params(_lib.ACTOR_TARGET), flat_actor(ref, ref.actor_target), rtol=1e-5, atol=1e-5, name="actor target")
+
+
+def test_actor_update_delay_other_than_two():
+    """actor_update_delay = 1 and 3 through the fused step: counters / schedule of orchestrator.py:345-349."""
+    for delay in (1, 3):
+        ref, eng, (o, a, bound) = make_pair("sac", "hopper", 64, actor_update_delay=delay)
+        obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(300, o, a, bound, seed=41)]
+        eng.rb_extend(obs, act, rew, nobs, done)
+        for i in range(2 * (delay + 1)):
+            eng.step(i % (delay + 1) == 0)
+        _, _, ta = eng.get_adam_state(_lib.ACTOR)
+        _, _, tq = eng.get_adam_state(_lib.CRITICS)
+        assert tq == 2 * (delay + 1) and ta == 2 * delay
+        assert all(np.isfinite(v) for v in eng.read_metrics().values())
