@@ -1,21 +1,22 @@
 // Device code of the SAC/TD3 update engine for gfx950 (MI355X, CDNA4).  wave = 64 lanes throughout.
 //
-// The whole path is latency-bound (B <= 4096 rows, 256-wide layers: everything lives in L2 / Infinity Cache), so
-// every kernel is built the same way: issue ALL of its global loads first (one memory round trip), park them in
-// LDS, then compute out of LDS/registers; reductions are DPP (no ds_bpermute); nothing waits on the host.
+// The whole path is latency-bound (B <= 4096 rows, 256-wide layers: everything lives in the Infinity Cache), so every
+// kernel is built the same way: issue ALL of its global loads first (one memory round trip), compute out of
+// registers / LDS, reduce with DPP (no ds_bpermute), never index a local array dynamically (that is scratch memory).
 //
 //   k_gather          replay ring -> batch slot (float4 record chunks, Philox index draw fused)
-//   k_nt              Y = pro(A) W^T + b on v_mfma_f32_16x16x4_f32: 16-row x 64-col block, operands staged in LDS;
-//                     pro = LayerNorm+ReLU of the producing layer fused into the A tile; optionally the FIRST
-//                     layer of the MLP (x W1^T + b1) is computed in the same kernel (small input widths)
-//   k_nn              dX = dY W                      (same tiling, W strip staged in LDS)
-//   k_tn              dW = dY^T X  (+ bias gradient, + LayerNorm-affine / head gradients from row partials)
+//   k_nt / k_nt_wide  Y = pro(A) W^T + b on v_mfma_f32_16x16x4_f32; pro = LayerNorm+ReLU of the producing layer applied to
+//                     the A fragments in registers; optionally the FIRST layer (x W1^T + b1) is computed in the same kernel
+//                     straight into those fragments (narrow inputs); W tiles parked in LDS, block shape picked per launch
+//   k_nn              dX = dY W                     (16 x 16 tile per block, reduction split over the 4 waves)
+//   k_tn              dW = dY^T X for every weight of an update in one launch (+ bias gradient, LayerNorm-affine / head
+//                     gradients from row partials) with the Adam step, Polyak update and loss finalisation in the epilogue
 //   k_actor_tail      LN+ReLU -> head (MFMA, K split over the 4 waves) -> tanh-Gaussian sample + log-prob | TD3 policy
 //   k_critic_tail     twin target Q -> min/mix -> entropy -> Bellman target -> twin MSE -> dQ -> head bwd -> LN bwd
 //   k_actorq_tail     twin Q(s, pi(s)) -> min -> actor loss -> dQ routing -> head bwd -> LN bwd
 //   k_actor_head_bwd  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd (MFMA) -> LN bwd
-//   k_ln_bwd          LN+ReLU backward of hidden layer 1
-//   k_adam / k_polyak / k_alpha_step / k_gradnorm   flat optimiser kernels
+//   k_ln_bwd          LN+ReLU backward of hidden layer 1 (+ the dQ/da slice product of the actor update)
+//   k_adam / k_polyak / k_alpha_step / k_gradnorm   flat optimiser kernels (stand-alone forms)
 // Row kernels: 256 threads = 16 rows x 16 threads; thread (row, sub) owns columns {4*sub + 64*q + e}.
 // Math follows oracle/manual_grads.py (which is checked against autograd) line by line.
 #pragma once
