@@ -168,6 +168,15 @@ def main():
         fl = 4 * 2.0 * w["batch"] * 256 * ((w["o"] + w["a"]) + 256)
         out["roofline_mfma"] = {"kernel": "k_nt (4-net critic trunk)", "bound": "mfma", "achieved": fl / us_t * 1e-6, "peak": 157.3,
                                 "unit": "TFLOP/s", "frac": fl / us_t * 1e-6 / 157.3, "flops_per_launch": fl, "avg_launch_us": us_t}
+        # acting side (agents/agent.py:172-181): one predict round trip = H2D of the observations, 2 kernels, D2H + sync
+        import numpy as np
+        ob = np.zeros((4, w["o"]), np.float32)
+        for _ in range(20):
+            eng.predict(ob, True)
+        tp = time.perf_counter()
+        for _ in range(300):
+            eng.predict(ob, True)
+        out["predict_round_trip_us"] = (time.perf_counter() - tp) / 300 * 1e6
         if world == 1 and not args.no_baselines:
             # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
             sweep = {}

@@ -1,0 +1,87 @@
+"""The rollout / training-loop mirrors (loop.py) against the restated reference generator (oracle/rollout_ref.py)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle.rollout_ref import ListBuffer, segment_ref
+from sac_td3_cudagraphs_pytorch_amd import loop
+
+
+class FakeAgent:
+    """Deterministic stand-in for the learner: predict() is a fixed function of the observation."""
+
+    def __init__(self, a):
+        self.rb, self.timesteps_so_far, self.a, self.calls = ListBuffer(), 0, a, 0
+
+    def predict(self, td, *, explore):
+        self.calls += 1
+        ob = np.asarray(td["observations"], np.float32)
+        return np.tanh(ob[:, : self.a] * 0.7 + 0.1 * self.calls).astype(np.float32)
+
+
+@pytest.mark.parametrize("segment_len,action_repeat", [(1, 1), (3, 1), (2, 2)])
+def test_segment_writes_the_same_rows_as_the_restated_reference(segment_len, action_repeat):
+    o, a, n = 5, 2, 4
+    runs = []
+    for gen_fn in (loop.segment, segment_ref):
+        env = loop.SyntheticVecEnv(o, a, n, horizon=7, term_at=2.5)
+        env.action_space.seed(3)
+        agent = FakeAgent(a)
+        gen = gen_fn(env, agent, seed=11, segment_len=segment_len, learning_starts=40, action_repeat=action_repeat)
+        for _ in range(40):
+            next(gen)
+            agent.timesteps_so_far += segment_len * n
+        runs.append(agent.rb.rows)
+    got, want = runs
+    assert len(got) == len(want) > 100
+    saw_trunc = saw_term = False
+    for g, w in zip(got, want):
+        assert set(g) == set(w) == {"observations", "next_observations", "actions", "rewards", "terminations", "dones"}
+        for k in w:
+            assert g[k].dtype == w[k].dtype and np.array_equal(g[k], w[k]), k
+        saw_term |= bool(w["dones"].any())
+    assert saw_term                                    # terminations occurred and were written as `dones`
+
+
+def test_truncation_stores_the_final_observation_not_the_reset_one():
+    o, a, n = 3, 1, 2
+    env = loop.SyntheticVecEnv(o, a, n, horizon=4, term_at=1e9)     # only truncations
+    agent = FakeAgent(a)
+    gen = loop.segment(env, agent, seed=0, segment_len=1, learning_starts=0, action_repeat=1)
+    for _ in range(9):
+        next(gen)
+    rows = agent.rb.rows
+    # rows come in groups of n per step; step 4 (index 3) is the truncating one
+    trunc_row, after = rows[3 * n], rows[4 * n]
+    assert not trunc_row["dones"].any()                # a time-limit is not a termination (orchestrator.py:107-108)
+    # the next episode starts from a fresh observation, which is NOT what was stored as next_observations
+    assert not np.allclose(trunc_row["next_observations"], after["observations"])
+
+
+@pytest.mark.gpu
+def test_train_loop_drives_the_engine_end_to_end():
+    import torch
+    import sac_td3_cudagraphs_pytorch_amd as P
+    from oracle.sac_td3_ref import Hps
+    o, a, n = 11, 3, 4
+    cfg = SimpleNamespace(**{**Hps.sac(batch_size=64).__dict__, "seed": 0, "num_envs": n, "action_repeat": 1, "learning_starts": 400,
+                             "num_timesteps": 2400, "eval_every": 800, "cudagraphs": True, "rb_capacity": 5000})
+    logs = []
+    for fused in (True, False):
+        env = loop.SyntheticVecEnv(o, a, n)
+        env.action_space.seed(0)
+        torch.manual_seed(0)
+        agent = P.Agent({"ob_shape": (n, o), "ac_shape": (n, a)}, np.full(a, -1.0, np.float32), np.full(a, 1.0, np.float32),
+                        torch.device("cuda:0"), cfg, P.ReplayBuffer(cfg.rb_capacity))
+        evals = []
+        m = loop.train(cfg, env, agent, fused=fused, on_eval=lambda ag, ts: evals.append(ts))
+        assert agent.timesteps_so_far == 2404 and len(agent.rb) == 2404
+        assert agent.qnet_updates_so_far == 501            # iterations after learning_starts (orchestrator.py:329-342)
+        assert agent.actor_updates_so_far == 2 * 167       # i % 3 == 0 on the global iteration counter (:345-349)
+        assert evals == [800, 1600, 2400] and all(np.isfinite(v) for v in m.values())
+        ep = next(loop.episode(loop.SyntheticVecEnv(o, a, 1), agent, seed=5))
+        assert ep["length"] > 0 and np.isfinite(ep["return"])
+        logs.append((m, agent.engine.get_params(0)))
+    # same seeds, same Philox streams, same kernels: the fused and the call-by-call loops are the same computation
+    assert logs[0][0] == logs[1][0] and np.array_equal(logs[0][1], logs[1][1])
