@@ -23,6 +23,10 @@
 static thread_local std::string g_create_error;
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// ceil(2^32 / d) if it divides every n < n_max exactly via mulhi (n_max * d < 2^32), else 0 (= use a real division)
+static inline unsigned magic_div(unsigned d, unsigned long long n_max) {
+  return (d > 1 && n_max * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+}
 
 static NetLayout make_layout(int K, int nh) {
   NetLayout L{};
@@ -201,7 +205,7 @@ static void tn_fin(TnProb& q, int slot, int off) { q.fin_slot[q.nfin] = slot; q.
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
 struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
-struct TrunkTicks { int* tick0; int* tick1; float* adam_out; float lr; };
+struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; };
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
@@ -215,14 +219,15 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   if (K <= 64) {
     for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].x;
     h.ld_in = ldx; h.in_ns = 0; h.K1 = K; h.oW1 = L.W1; h.ldw1 = L.ld1; h.oB1 = L.b1;
-    h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
+    h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.adam_pw = tk.adam_pw; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
+    h.w1_magic = magic_div((unsigned)L.ld1, 4u * HID * (unsigned)L.ld1);
     return launch_nt(e, s, pro, true, h, nets);
   }
   NtArgs g{};
   g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
   g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
   for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
-  g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
+  g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
   RCCHK(launch_nt(e, s, 0, false, g, nets));
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
@@ -258,14 +263,15 @@ static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, in
   g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
   g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
   g.B = e->B; g.len_override = identity_len;
+  g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)e->B * e->rec4 + 1);
   hipLaunchKernelGGL(k_gather, dim3(gather_blocks((long)e->B * e->rec4)), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static AdamArgs adam_args(sactd3_engine* e, float* p, const float* g, float* m, float* v, long n, const int* t, float lr) {
+static AdamArgs adam_args(sactd3_engine* e, float* p, const float* g, float* m, float* v, long n, const float* adam) {
   AdamArgs a{};
-  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.t = t; a.lr = lr;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.adam = adam;
   a.b1 = e->cfg.adam_beta1; a.b2 = e->cfg.adam_beta2; a.eps = e->cfg.adam_eps;
   return a;
 }
@@ -286,7 +292,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
   {
     const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g,
-                        TrunkTicks{&e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, c.qnets_lr}));
+                        TrunkTicks{&e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr}));
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
     RCCHK(launch_tail(e, s, t));
@@ -296,7 +302,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
      //  ROCm 7.2 -- cross-stream edges are far dearer than the 1.7 us of a linear edge -- so graphs stay linear.)
     const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
                            {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
   }
   {
     CriticTail t{};
@@ -349,14 +355,14 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   const bool clip = c.clip_norm > 0.f;
   {  // a_pi, logp = pi(s) with stores for the backward pass
     const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, c.actor_lr}));
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
     ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
     t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
     RCCHK(launch_tail(e, s, t));
   }
   {  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
     const TrunkGrp g{e->Xp, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
   }
   {
     ActorQTail t{};
@@ -422,7 +428,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     NormArgs n{e->Ga, (long)e->La.size, c.clip_norm, e->gscale};
     hipLaunchKernelGGL(k_gradnorm, dim3(1), dim3(1024), 0, s, n);
     HIPCHK(hipGetLastError());
-    AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, &e->ctl->t_a, c.actor_lr);
+    AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, e->ctl->adam_a);
     a.gscale = e->gscale;
     a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_adam(e, s, a));
@@ -430,7 +436,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
   if (!td3) {
     if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
       const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
-      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
       RCCHK(launch_tail(e, s, t));
     }
@@ -559,6 +565,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   e->ldc = round_up(e->o + e->a, 4); e->ldo = round_up(e->o, 4);
   e->cx = e->ldc / 4; e->cn = e->ldo / 4;
   e->rec_f = round_up(e->ldc + e->ldo + 2, 16); e->rec4 = e->rec_f / 4;
+  if ((long long)e->B * e->rec4 >= (1ll << 31)) return e->fail(SACTD3_EINVAL, "batch_size x record size too large");
   e->La = make_layout(e->o, e->nh); e->Lc = make_layout(e->o + e->a, 1);
   e->nq_actor = td3 ? 1 : 2;
   e->nblk = (e->B + 15) / 16;
@@ -614,6 +621,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   HIPCHK(hipMemcpy(e->bias, hb.data() + 3 * e->a4, sizeof(float) * e->a4, hipMemcpyHostToDevice));
   DevCtl hc{};
   hc.seed = c.seed;
+  hc.pw_q[0] = hc.pw_q[1] = hc.pw_a[0] = hc.pw_a[1] = hc.pw_l[0] = hc.pw_l[1] = 1.0;
   HIPCHK(hipMemcpy(e->ctl, &hc, sizeof(hc), hipMemcpyHostToDevice));
   const float la0[4] = {logf(c.alpha_init), 0.f, 0.f, 0.f};   // agents/agent.py:128
   HIPCHK(hipMemcpy(e->la, la0, sizeof(la0), hipMemcpyHostToDevice));
@@ -738,6 +746,8 @@ int sactd3_set_adam_state(sactd3_engine* e, int which, const float* m, const flo
     if (m) HIPCHK(hipMemcpy(e->la + 1, m, sizeof(float), hipMemcpyHostToDevice));
     if (v) HIPCHK(hipMemcpy(e->la + 2, v, sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(&e->ctl->t_l, &st, sizeof(int), hipMemcpyHostToDevice));
+    const double pw[2] = {pow((double)e->cfg.adam_beta1, (double)st), pow((double)e->cfg.adam_beta2, (double)st)};
+    HIPCHK(hipMemcpy(e->ctl->pw_l, pw, sizeof(pw), hipMemcpyHostToDevice));
     return 0;
   }
   if (which != SACTD3_ACTOR && which != SACTD3_CRITICS) return e->fail(SACTD3_EINVAL, "no optimiser owns this parameter set");
@@ -746,6 +756,8 @@ int sactd3_set_adam_state(sactd3_engine* e, int which, const float* m, const flo
   if (m) RCCHK(write_arena(e, M, *L, nets, m, false));
   if (v) RCCHK(write_arena(e, V, *L, nets, v, false));
   HIPCHK(hipMemcpy(t, &st, sizeof(int), hipMemcpyHostToDevice));
+  const double pw[2] = {pow((double)e->cfg.adam_beta1, (double)st), pow((double)e->cfg.adam_beta2, (double)st)};
+  HIPCHK(hipMemcpy(which == SACTD3_ACTOR ? e->ctl->pw_a : e->ctl->pw_q, pw, sizeof(pw), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -925,7 +937,7 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
   HIPCHK(hipMemcpyAsync(e->p_x, e->h_obs, sizeof(float) * (size_t)n * e->ldo, hipMemcpyHostToDevice, e->stream));
   {
     const TrunkGrp g{e->p_x, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
-    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, 0.f}));
+    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
   }
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
   ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr);
@@ -1012,7 +1024,7 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
     if (!strcmp(kernel, "trunk_critics")) {   // the 4-net hidden-layer launch of update_qnets (no state is modified)
       const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
                              {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
-      return enqueue_trunk(e, e->stream, e->ldc, e->o + e->a, e->B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, 0.f});
+      return enqueue_trunk(e, e->stream, e->ldc, e->o + e->a, e->B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f});
     }
     return e->fail(SACTD3_EINVAL, "time_kernel: unknown kernel (gather | polyak | trunk_critics)");
   };
@@ -1033,6 +1045,7 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes) {
   if (!e || !usec || batch < 1 || iters < 1) return SACTD3_EINVAL;
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "gather sweep: buffer is empty");
+  if ((long long)batch * e->rec4 >= (1ll << 31)) return e->fail(SACTD3_EINVAL, "gather sweep: batch too large");
   float *X = nullptr, *Xn = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;
   const size_t rows = batch;
   hipError_t he = hipSuccess;
@@ -1045,6 +1058,7 @@ int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec
     GatherArgs g{};
     g.ring = (const float4*)e->ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = ix;
     g.X = (float4*)X; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
+    g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)batch * e->rec4 + 1);
     const dim3 grid(gather_blocks((long)batch * e->rec4));
     hipEvent_t t0, t1;
     hipEventCreate(&t0); hipEventCreate(&t1);

@@ -53,6 +53,7 @@ struct DevCtl {
   int pad_;
   float metrics[8];
   float adam_q[2], adam_a[2];   // (lr / (1 - b1^t), sqrt(1 - b2^t)) of the critics' / actor's current step
+  double pw_q[2], pw_a[2], pw_l[2];   // running b1^t, b2^t of the three optimisers (no pow() on the critical path)
 };
 
 struct NetLayout {   // float offsets inside one net's parameter block (all multiples of 4)
@@ -62,6 +63,18 @@ struct NetLayout {   // float offsets inside one net's parameter block (all mult
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
+// exact n / d for n * d < 2^32 with magic = ceil(2^32 / d) (host-computed); magic == 0: plain division
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned magic) { return magic ? __umulhi(n, magic) : n / d; }
+// one thread: advance an optimiser's step count and publish the step's Adam scalars (torch.optim.Adam bias corrections)
+__device__ __forceinline__ void adam_tick(int* t, double* pw, float* out, float lr, float b1, float b2) {
+  *t += 1;
+  if (out) {
+    const double p1 = pw[0] * (double)b1, p2 = pw[1] * (double)b2;
+    pw[0] = p1; pw[1] = p2;
+    out[0] = (float)((double)lr / (1.0 - p1));
+    out[1] = (float)sqrt(1.0 - p2);
+  }
+}
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
@@ -180,6 +193,7 @@ struct GatherArgs {
   float4* X; float4* Xn;                  // row stride = cx chunks
   float* rew; float* done;
   int B; int len_override;                // len_override >= 0: use it instead of ctl->rb_len (staged batches)
+  unsigned rec4_magic;                    // ceil(2^32 / rec4) when B * rec4 * rec4 < 2^32, else 0
 };
 
 #define GATHER_CPT 4    // float4 chunks per thread: loads in flight per lane
@@ -187,14 +201,15 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs p) {
   const int inject = p.ctl->inject_idx;
   const unsigned long long seed = p.ctl->seed;
   const int ctr = p.ctl->sample_ctr, len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
-  const long g0 = ((long)blockIdx.x * 256 + threadIdx.x);
-  const long total = (long)p.B * p.rec4, stride = (long)gridDim.x * 256;
+  const unsigned g0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = gridDim.x * 256u;   // host guarantees B * rec4 < 2^31
   int bb[GATHER_CPT], cc[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT];
 #pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) {            // consecutive threads -> consecutive chunks of a record
-    const long g = g0 + u * stride;
+    const unsigned g = g0 + u * stride;
     on[u] = g < total;
-    bb[u] = on[u] ? (int)(g / p.rec4) : 0; cc[u] = on[u] ? (int)(g % p.rec4) : 0;
+    const unsigned q = on[u] ? fast_div(g, (unsigned)p.rec4, p.rec4_magic) : 0u;
+    bb[u] = (int)q; cc[u] = on[u] ? (int)(g - q * (unsigned)p.rec4) : 0;
     int id;
     if (inject) id = p.idx[bb[u]];
     else {
@@ -277,7 +292,8 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int K1, oW1, ldw1, oB1;                   // FUSE1: A rows = x W1^T + b1 computed here (x: [M][ld_in], K1 <= 64)
   long act_ns;                              // net stride of xh_out / h_out ([M][256]); rstd_out is [nets][M]
   int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
-  float* adam_out; float lr, b1, b2;        // with tick0: publish this step's Adam scalars (t = new *tick0)
+  float* adam_out; double* adam_pw; float lr, b1, b2;   // with tick0: publish this step's Adam scalars
+  unsigned w1_magic;                        // ceil(2^32 / ldw1) for the W1 parking index arithmetic
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -312,14 +328,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int r = lane & 15, kq = lane >> 4;
   const int mt = wave / KS, ks = wave % KS;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) {
-      const int ts = *p.tick0 + 1;
-      *p.tick0 = ts;
-      if (p.adam_out) {
-        p.adam_out[0] = (float)((double)p.lr / (1.0 - pow((double)p.b1, (double)ts)));
-        p.adam_out[1] = (float)sqrt(1.0 - pow((double)p.b2, (double)ts));
-      }
-    }
+    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
     if (p.tick1) *p.tick1 += 1;
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int f = t + 256 * u;
-      if (f < w1n) { const int e = 4 * f, row = e / p.ldw1, col = e - row * p.ldw1; st4(W1s + row * W1S + col, w1r[u]); }
+      if (f < w1n) { const int e = 4 * f, row = (int)fast_div((unsigned)e, (unsigned)p.ldw1, p.w1_magic), col = e - row * p.ldw1; st4(W1s + row * W1S + col, w1r[u]); }
     }
   }
   if (t < 192) st4(vec + 4 * t, vr);
@@ -493,14 +502,7 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) {
-      const int ts = *p.tick0 + 1;
-      *p.tick0 = ts;
-      if (p.adam_out) {
-        p.adam_out[0] = (float)((double)p.lr / (1.0 - pow((double)p.b1, (double)ts)));
-        p.adam_out[1] = (float)sqrt(1.0 - pow((double)p.b2, (double)ts));
-      }
-    }
+    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
     if (p.tick1) *p.tick1 += 1;
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
 // ------------------------------------------------------------------------------------------------ optimiser
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; long n;   // n multiple of 4
-  const int* t; float lr, b1, b2, eps;
+  const float* adam; float b1, b2, eps;  // adam: (lr / (1 - b1^t), sqrt(1 - b2^t))
   const float* gscale;                   // optional gradient scale (clip_grad_norm_)
   float* targ; float tau;                // optional fused Polyak of the same arena
   const float* loss_part; int loss_n; int loss_stride; int loss_off; float loss_scale; float* loss_dst;
@@ -1188,9 +1190,7 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-  const int t = *a.t;
-  const double bc1 = 1.0 - pow((double)a.b1, (double)t), bc2 = 1.0 - pow((double)a.b2, (double)t);
-  const float step = (float)((double)a.lr / bc1), sq2 = (float)sqrt(bc2);
+  const float step = a.adam[0], sq2 = a.adam[1];   // published by the first kernel of the update (adam_tick)
   const float gs = a.gscale ? *a.gscale : 1.0f;
   const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (long)gridDim.x * 1024) {
@@ -1244,12 +1244,12 @@ __global__ __launch_bounds__(256) void k_alpha_step(AlphaArgs a) {
       const float mean_term = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
       const float g = expf(la) * mean_term;          // d/dlog_alpha of alpha * mean_term; also the loss value
       a.ctl->metrics[2] = g;
-      const int t = a.ctl->t_l + 1; a.ctl->t_l = t;
+      float sc[2];
+      adam_tick(&a.ctl->t_l, a.ctl->pw_l, sc, a.lr, a.b1, a.b2);
       float m = a.la[1], v = a.la[2];
       m = m + (g - m) * (1.0f - a.b1);
       v = v * a.b2 + g * g * (1.0f - a.b2);
-      const double bc1 = 1.0 - pow((double)a.b1, (double)t), bc2 = 1.0 - pow((double)a.b2, (double)t);
-      la -= (float)((double)a.lr / bc1) * (m / (sqrtf(v) / (float)sqrt(bc2) + a.eps));
+      la -= sc[0] * (m / (sqrtf(v) / sc[1] + a.eps));
       a.la[0] = la; a.la[1] = m; a.la[2] = v;
     }
     a.ctl->metrics[3] = expf(la);
