@@ -153,11 +153,18 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 // ------------------------------------------------------------------------------------------------ launches
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
-template <int PRO, bool F1>
+template <int PRO, bool F1, int C1>
 static void launch_nt_ks(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
-  if (ks == 4) hipLaunchKernelGGL((k_nt<PRO, F1, 4>), grid, dim3(256), 0, s, g);
-  else if (ks == 2) hipLaunchKernelGGL((k_nt<PRO, F1, 2>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((k_nt<PRO, F1, 1>), grid, dim3(256), 0, s, g);
+  if (ks == 4) hipLaunchKernelGGL((k_nt<PRO, F1, 4, C1>), grid, dim3(256), 0, s, g);
+  else if (ks == 2) hipLaunchKernelGGL((k_nt<PRO, F1, 2, C1>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((k_nt<PRO, F1, 1, C1>), grid, dim3(256), 0, s, g);
+}
+template <int PRO>
+static void launch_nt_f1(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
+  const int c1 = (g.K1 + 15) / 16;
+  if (c1 <= 1) launch_nt_ks<PRO, true, 1>(s, ks, grid, g);
+  else if (c1 == 2) launch_nt_ks<PRO, true, 2>(s, ks, grid, g);
+  else launch_nt_ks<PRO, true, 4>(s, ks, grid, g);
 }
 // pro == 0: the generic-K form (unfused first layer).  Otherwise K == 256 and the block shape (16 / 32 / 64 rows x 16
 // columns) is chosen so that the launch has about one block per CU.
@@ -170,8 +177,8 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     const int ks = tiles >= 4 * e->num_cus ? 1 : (tiles >= 2 * e->num_cus ? 2 : 4);
     const int rb = 64 / ks;
     const dim3 grid((unsigned)(((g.M + rb - 1) / rb) * tiles_n), 1, (unsigned)nets);
-    if (fuse1) { if (pro == 1) launch_nt_ks<1, true>(s, ks, grid, g); else launch_nt_ks<2, true>(s, ks, grid, g); }
-    else { if (pro == 1) launch_nt_ks<1, false>(s, ks, grid, g); else launch_nt_ks<2, false>(s, ks, grid, g); }
+    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, g); else launch_nt_f1<2>(s, ks, grid, g); }
+    else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, g); else launch_nt_ks<2, false, 0>(s, ks, grid, g); }
   }
   HIPCHK(hipGetLastError());
   return 0;

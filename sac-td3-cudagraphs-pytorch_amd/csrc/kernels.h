@@ -315,7 +315,7 @@ __device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 
 // The host picks KS so that a launch has about one block per CU: what a CU can fetch per clock (~13 B coalesced,
 // ~7 B in 64-byte pieces) bounds these kernels, so W tiles (and the whole of W1) are fetched ONCE per block with
 // fully coalesced loads, parked in LDS and shared by the block's waves.
-template <int PRO, bool FUSE1, int KS>
+template <int PRO, bool FUSE1, int KS, int C1>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   constexpr int RB = 64 / KS, CW = 16 / KS, NP = 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
   constexpr int W1S = 68;                                                   // LDS row stride of W1 (K1 <= 64)
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   // ---- 1. every global load, coalesced where the data is shared by the block
-  float4 w2r[4], w1r[16], vr = f4(0.f), xv[4], av[CW];
+  float4 w2r[4], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {                              // W tile: 16 rows x 256 floats, one row per wave-instruction
     const int i = t + 256 * u, row = i >> 6, c4 = i & 63, n = min(n0 + row, p.N - 1);
@@ -351,15 +351,14 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int w1n = FUSE1 ? (HID * p.ldw1) >> 2 : 0;           // float4s of W1 (rows are 16-byte multiples, contiguous)
   if (FUSE1) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 4 * C1; ++u) {                        // ldw1 <= 16 C1 floats -> at most 4 C1 float4 per thread
       const int f = t + 256 * u;
       w1r[u] = f < w1n ? ld4(Pn + p.oW1 + 4 * (long)f) : f4(0.f);
     }
-    const int C1 = (p.K1 + 15) >> 4;
 #pragma unroll
-    for (int c1 = 0; c1 < 4; ++c1) {
+    for (int c1 = 0; c1 < C1; ++c1) {
       const int k = 16 * c1 + 4 * kq;
-      xv[c1] = (c1 < C1 && k < p.K1) ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
+      xv[c1] = k < p.K1 ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
     }
   } else {
 #pragma unroll
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   // ---- 2. park the shared operands in LDS (W1 first: the first layer only needs W1, x, b1)
   if (FUSE1) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 4 * C1; ++u) {
       const int f = t + 256 * u;
       if (f < w1n) { const int e = 4 * f, row = (int)fast_div((unsigned)e, (unsigned)p.ldw1, p.w1_magic), col = e - row * p.ldw1; st4(W1s + row * W1S + col, w1r[u]); }
     }
@@ -385,18 +384,16 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   if (FUSE1) {
     // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
     // z1[m][16 (ks CW + c) + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer
-    const int C1 = (p.K1 + 15) >> 4;
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const int tile = ks * CW + c;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c1 = 0; c1 < 4; ++c1)
-        if (c1 < C1) {
-          const int k = 16 * c1 + 4 * kq;
-          const float4 wf = k < p.ldw1 ? ld4(W1s + (tile * 16 + r) * W1S + k) : f4(0.f);
-          MFMA4(z, wf, xv[c1]);
-        }
+      for (int c1 = 0; c1 < C1; ++c1) {
+        const int k = 16 * c1 + 4 * kq;
+        const float4 wf = k < p.ldw1 ? ld4(W1s + (tile * 16 + r) * W1S + k) : f4(0.f);
+        MFMA4(z, wf, xv[c1]);
+      }
       const float4 b1 = ld4(vec + tile * 16 + 4 * kq);
       av[c] = make_float4(z[0] + b1.x, z[1] + b1.y, z[2] + b1.z, z[3] + b1.w);
     }
