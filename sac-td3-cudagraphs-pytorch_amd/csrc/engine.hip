@@ -354,13 +354,15 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
 }
 
 // agents/agent.py:244-318.  j = index of this actor update inside the iteration (selects the noise buffers).
-static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
+// head_done: this update's policy sample was already produced by the previous update's dual tail (fused iteration);
+// merge_next: produce the NEXT update's policy sample together with this update's temperature draw.
+static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
   const bool clip = c.clip_norm > 0.f;
-  {  // a_pi, logp = pi(s) with stores for the backward pass
+  if (!head_done) {  // a_pi, logp = pi(s) with stores for the backward pass
     const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
     ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
@@ -441,7 +443,19 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j) {
     RCCHK(launch_adam(e, s, a));
   }
   if (!td3) {
-    if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
+    if (c.autotune && merge_next) {
+      // The temperature draw (agent.py:297-299) and the next actor update's policy sample (agent.py:254) both go through
+      // the SAME freshly updated actor on the SAME observations: one trunk launch (with the next update's backward
+      // stores and Adam tick) and one tail launch with two draws.  Streams: temperature (ctr, 32), policy (ctr + 1, 16),
+      // exactly what the two separate launches would consume.
+      const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
+      const int sb_a_next = SACTD3_SITE_ACTOR0 + ((j + 1) & 1);
+      ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a_next, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+      t.obs_src = e->X; t.lds = e->ldc; t.ctr_add = 1;
+      t.dual = 1; t.site_buf2 = sb_l; t.site_code2 = 32u; t.eps2 = e->eps[sb_l]; t.logp2 = e->logp_al;
+      RCCHK(launch_tail(e, s, t));
+    } else if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
       const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
       RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
@@ -476,8 +490,11 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
   RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr));
-  if (do_actor)
-    for (int j = 0; j < e->cfg.actor_update_delay; ++j) RCCHK(enqueue_update_actor(e, s, j));
+  if (do_actor) {
+    const int n = e->cfg.actor_update_delay;
+    const bool can_merge = !td3 && e->cfg.autotune;
+    for (int j = 0; j < n; ++j) RCCHK(enqueue_update_actor(e, s, j, can_merge && j > 0, can_merge && j + 1 < n));
+  }
   if (do_polyak && td3) RCCHK(enqueue_polyak(e, s, true, true));
   return 0;
 }

@@ -750,15 +750,22 @@ struct ActorTail {
   float* h2; float* xh2; float* rstd2; float* tg;   // train stores: h2, xhat2 [B][HID], rstd2 [B], tg [B][4][a4] (t, std, y)
   int a4;
   float td3_std, td3_c, noise_std;
+  int ctr_add;                           // the primary draw uses stream counter *ctr + ctr_add
+  // SAC, dual mode: a SECOND, gradient-free draw through the same head outputs (the temperature step's fresh sample,
+  // agents/agent.py:297-299) sharing this kernel with the next actor update's sample: only its log-prob is kept
+  int dual; int site_buf2; unsigned site_code2; float* eps2; float* logp2;
 };
 
 // the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
-__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int bc, int b, int j, bool valid) {
-  if (!need_eps) return 0.f;
-  if (p.ctl->inject_eps[p.site_buf]) return p.eps[(long)bc * p.a + j];
-  const float e = philox_normal(p.ctl->seed, (unsigned)*p.ctr, p.site_code, (unsigned)(bc * p.a + j));
-  if (valid) p.eps[(long)b * p.a + j] = e;
+__device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr_add,
+                                           int bc, int b, int j, bool valid) {
+  if (p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
+  const float e = philox_normal(p.ctl->seed, (unsigned)(*p.ctr + ctr_add), site_code, (unsigned)(bc * p.a + j));
+  if (valid) eps[(long)b * p.a + j] = e;
   return e;
+}
+__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int bc, int b, int j, bool valid) {
+  return need_eps ? tail_draw(p, p.site_buf, p.site_code, p.eps, p.ctr_add, bc, b, j, valid) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
@@ -789,6 +796,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   const float e_bh0 = p.P[p.L.bh + j0], e_bh1 = p.sac ? p.P[p.L.bh + p.a + j0] : 0.f;
   const float e_sc = p.scale[j0], e_bi = p.bias[j0];
   const float e_eps = sub < p.a ? tail_noise(p, need_eps, bc, b, j0, valid) : 0.f;
+  const float e_eps2 = (p.dual && sub < p.a) ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j0, valid) : 0.f;
   STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   }
   __syncthreads();
   STAMP(3);
-  float lp = 0.f;
+  float lp = 0.f, lp2 = 0.f;
   for (int j = sub; j < p.a; j += 16) {
     const bool first = j == sub;
     const float* u = Up + row * 64;
@@ -846,6 +854,11 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       float l = -(dx * dx) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;
       l -= logf(sc * (1.0f - yt * yt) + 1e-6f);
       lp += l;
+      if (p.dual) {                                      // second draw: log-prob only
+        const float e2 = first ? e_eps2 : tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j, valid);
+        const float x2 = u0 + e2 * sd, y2 = tanhf(x2), d2 = x2 - u0;
+        lp2 += -(d2 * d2) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f - logf(sc * (1.0f - y2 * y2) + 1e-6f);
+      }
       if (p.mode == 1) act = tanhf(u0) * sc + bi;
       if (p.train && valid) {
         float* tg = p.tg + (long)b * 4 * p.a4;
@@ -868,6 +881,10 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   if (p.sac && p.logp) {
     lp = row16_sum(lp);
     if (sub == 0 && valid) p.logp[b] = lp;
+  }
+  if (p.dual) {
+    lp2 = row16_sum(lp2);
+    if (sub == 0 && valid) p.logp2[b] = lp2;
   }
   STAMP(5);
 }
