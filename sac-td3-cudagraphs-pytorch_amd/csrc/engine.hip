@@ -174,7 +174,8 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     hipLaunchKernelGGL(k_nt_wide, dim3((unsigned)(tiles_m * tiles_n), 1, (unsigned)nets), dim3(256), 0, s, g);
   } else {
     const int tiles = tiles_m * tiles_n * nets;
-    const int ks = tiles >= 4 * e->num_cus ? 1 : (tiles >= 2 * e->num_cus ? 2 : 4);
+    int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
+    if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) ks = v; }   // tuning aid
     const int rb = 64 / ks;
     const dim3 grid((unsigned)(((g.M + rb - 1) / rb) * tiles_n), 1, (unsigned)nets);
     if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, g); else launch_nt_f1<2>(s, ks, grid, g); }

@@ -318,9 +318,9 @@ __device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 
 template <int PRO, bool FUSE1, int KS, int C1>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   constexpr int RB = 64 / KS, CW = 16 / KS, NP = 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
-  constexpr int W1S = 68;                                                   // LDS row stride of W1 (K1 <= 64)
+  constexpr int W1S = 16 * (C1 > 0 ? C1 : 1) + 4;                           // LDS row stride of W1 (K1 <= 16 C1)
   __shared__ __attribute__((aligned(16))) float W2s[16 * AS];
-  __shared__ __attribute__((aligned(16))) float W1s[FUSE1 ? 256 * W1S : 4];
+  __shared__ __attribute__((aligned(16))) float W1s[FUSE1 ? HID * W1S : 4];
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
@@ -625,6 +625,8 @@ __device__ __forceinline__ void adam_commit(const TnArgs& p, long off, float g, 
 
 __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
+  __shared__ __attribute__((aligned(16))) float Xs[256 * YS];
   __shared__ float cred[16 * 17];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
@@ -648,31 +650,42 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       st[i] = (row < q.N && ecol < q.ldw) ? adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + ecol) : sv;
     }
   }
-  const float* Dc = q.dY + net * q.dy_ns + min(n0 + r, q.N - 1);
-  const bool kval = k0 + r < q.K;
-  const float* Xc = q.X + net * q.x_ns + min(k0 + r, q.K - 1);
-  const int chunks = (p.M + 15) >> 4;
+  // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
+  const float* dYn = q.dY + net * q.dy_ns;
+  const float* Xn = q.X + net * q.x_ns;
+  const int Nr = (q.N + 3) & ~3, Kr = (q.K + 3) & ~3;     // rows hold at least round4(.) floats
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float asum = 0.f;
-  for (int cb = 0; cb < chunks; cb += 16) {       // per batch: 4 chunks of 16 rows per wave, 32 loads in flight per lane
-    float4 a[4], b[4];
+  float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
+  for (int mb = 0; mb < p.M; mb += 256) {
+    if (mb) __syncthreads();
+    float4 vy[4], vx[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int c = cb + wave + 4 * u;
-      float* ap = &a[u].x; float* bp = &b[u].x;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int m = 16 * c + 4 * kq + jj;
-        const bool on = c < chunks && m < p.M;
-        const int mc = on ? m : 0;
-        const float av = Dc[(long)mc * q.ldy], xv = Xc[(long)mc * q.ldx];
-        ap[jj] = on ? av : 0.f;
-        bp[jj] = (on && kval) ? xv : 0.f;
-      }
+      const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
+      vy[u] = (m < p.M && n < Nr) ? zero_beyond(ld4(dYn + (long)m * q.ldy + n), n, q.N) : f4(0.f);
+      vx[u] = (m < p.M && k < Kr) ? zero_beyond(ld4(Xn + (long)m * q.ldx + k), k, q.K) : f4(0.f);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { asum += sum4(a[u]); MFMA4(acc, a[u], b[u]); }
+    for (int u = 0; u < 4; ++u) {
+      const int i = t + 256 * u;
+      st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]);
+      st4(Xs + (i >> 2) * YS + 4 * (i & 3), vx[u]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                          // wave w: 16-row chunks w, w+4, w+8, w+12 of this slab
+      const float* y0 = Ys + (16 * (wave + 4 * u) + 4 * kq) * YS + r;
+      const float* x0 = Xs + (16 * (wave + 4 * u) + 4 * kq) * YS + r;
+      const float4 a = make_float4(y0[0], y0[YS], y0[2 * YS], y0[3 * YS]);
+      const float4 b = make_float4(x0[0], x0[YS], x0[2 * YS], x0[3 * YS]);
+      MFMA4(acc, a, b);
+    }
+    if (tk == 0 && q.b_off >= 0) {
+      const int col = t & 15, part = t >> 4;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asum += Ys[(part * 16 + i) * YS + col];
+    }
   }
   acc = splitk_reduce(red, acc, wave, lane);
   if (wave == 0 && ecol < q.ldw) {
