@@ -112,11 +112,19 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     import torch
+    # rehearsal knobs (one-GPU boxes): SACTD3_BENCH_BACKEND=gloo and SACTD3_BENCH_DEVICE=0 let N ranks share one card
+    backend = os.environ.get("SACTD3_BENCH_BACKEND", "nccl")
+    if "SACTD3_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["SACTD3_BENCH_DEVICE"])
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     eng = make_engine(w, seed=rank, device_id=local)  # seed = GPU index, one independent learner per GPU
     delay = 2
@@ -136,7 +144,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank defines the job's time
         dt = float(t.item())
         dist.barrier()
