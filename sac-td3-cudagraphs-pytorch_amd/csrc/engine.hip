@@ -153,6 +153,19 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 // ------------------------------------------------------------------------------------------------ launches
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
+// one float4 chunk per thread while that still fills the chip; GATHER_CPT chunks (loads in flight) per thread beyond
+static unsigned gather_blocks(long chunks) {
+  const long one = (chunks + 255) / 256;
+  return (unsigned)(one <= 4096 ? one : (chunks + 256L * GATHER_CPT - 1) / (256L * GATHER_CPT));
+}
+static GatherArgs gather_args(sactd3_engine* e, const float* ring, int identity_len) {
+  GatherArgs g{};
+  g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
+  g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
+  g.B = e->B; g.len_override = identity_len;
+  g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)e->B * e->rec4 + 1);
+  return g;
+}
 template <int PRO, bool F1, int C1>
 static void launch_nt_ks(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
   if (ks == 4) hipLaunchKernelGGL((k_nt<PRO, F1, 4, C1>), grid, dim3(256), 0, s, g);
@@ -177,9 +190,11 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
     if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) ks = v; }   // tuning aid
     const int rb = 64 / ks;
-    const dim3 grid((unsigned)(((g.M + rb - 1) / rb) * tiles_n), 1, (unsigned)nets);
-    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, g); else launch_nt_f1<2>(s, ks, grid, g); }
-    else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, g); else launch_nt_ks<2, false, 0>(s, ks, grid, g); }
+    NtArgs gg = g;
+    gg.nt_blocks = ((g.M + rb - 1) / rb) * tiles_n;
+    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks), 1, (unsigned)nets);
+    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, gg); else launch_nt_f1<2>(s, ks, grid, gg); }
+    else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, gg); else launch_nt_ks<2, false, 0>(s, ks, grid, gg); }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -213,7 +228,7 @@ static void tn_fin(TnProb& q, int slot, int off) { q.fin_slot[q.nfin] = slot; q.
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
 struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
-struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; };
+struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false; };
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
@@ -229,6 +244,10 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.ld_in = ldx; h.in_ns = 0; h.K1 = K; h.oW1 = L.W1; h.ldw1 = L.ld1; h.oB1 = L.b1;
     h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.adam_pw = tk.adam_pw; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
     h.w1_magic = magic_div((unsigned)L.ld1, 4u * HID * (unsigned)L.ld1);
+    if (tk.fuse_gather) {   // x = the s' field of the sampled records; extra blocks fill the batch slot (see NtArgs)
+      h.ring_rows = 1; h.ring_off = e->ldc; h.ga = gather_args(e, e->ring, -1);
+      h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
+    }
     return launch_nt(e, s, pro, true, h, nets);
   }
   NtArgs g{};
@@ -261,17 +280,8 @@ static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
   return 0;
 }
 
-// one float4 chunk per thread while that still fills the chip; GATHER_CPT chunks (loads in flight) per thread beyond
-static unsigned gather_blocks(long chunks) {
-  const long one = (chunks + 255) / 256;
-  return (unsigned)(one <= 4096 ? one : (chunks + 256L * GATHER_CPT - 1) / (256L * GATHER_CPT));
-}
 static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, int identity_len) {
-  GatherArgs g{};
-  g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
-  g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
-  g.B = e->B; g.len_override = identity_len;
-  g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)e->B * e->rec4 + 1);
+  const GatherArgs g = gather_args(e, ring, identity_len);
   hipLaunchKernelGGL(k_gather, dim3(gather_blocks((long)e->B * e->rec4)), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
@@ -291,7 +301,9 @@ static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
 }
 
 // agents/agent.py:183-242
-static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sample, float* fused_polyak_targ) {
+// fused_sample: this update opens a fused iteration and owns the replay sampling (orchestrator.py:338); with a narrow
+// observation the gather rides in the first trunk kernel, otherwise enqueue_step has launched k_gather just before.
+static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
@@ -299,10 +311,13 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool tick_sampl
   const float* Pact = td3 ? e->Ta : e->Pa;
   {
     const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g,
-                        TrunkTicks{&e->ctl->t_q, tick_sample ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr}));
+    const bool in_kernel_gather = fused_sample && e->o <= 64;
+    TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
+    tk.fuse_gather = in_kernel_gather;
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
+    if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
     RCCHK(launch_tail(e, s, t));
   }
   {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232).
@@ -487,7 +502,7 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 // orchestrator.py:337-352 as one sequence
 static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
-  RCCHK(enqueue_gather(e, s, e->ring, -1));
+  if (e->o > 64) RCCHK(enqueue_gather(e, s, e->ring, -1));   // narrow observations: the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
   RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr));

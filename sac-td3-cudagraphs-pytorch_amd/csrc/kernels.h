@@ -197,12 +197,12 @@ struct GatherArgs {
 };
 
 #define GATHER_CPT 4    // float4 chunks per thread: loads in flight per lane
-__global__ __launch_bounds__(256) void k_gather(GatherArgs p) {
+__device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block, unsigned nblocks) {
   const int inject = p.ctl->inject_idx;
   const unsigned long long seed = p.ctl->seed;
   const int ctr = p.ctl->sample_ctr, len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
-  const unsigned g0 = blockIdx.x * 256u + threadIdx.x;
-  const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = gridDim.x * 256u;   // host guarantees B * rec4 < 2^31
+  const unsigned g0 = block * 256u + threadIdx.x;
+  const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = nblocks * 256u;   // host guarantees B * rec4 < 2^31
   int bb[GATHER_CPT], cc[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT];
 #pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) {            // consecutive threads -> consecutive chunks of a record
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs p) {
     else { p.rew[b] = v[u].x; p.done[b] = v[u].y; }
   }
 }
+__global__ __launch_bounds__(256) void k_gather(GatherArgs p) { gather_body(p, blockIdx.x, gridDim.x); }
 
 __global__ void k_tick(int* a, int* b) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { if (a) *a += 1; if (b) *b += 1; }
@@ -294,6 +295,10 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
   float* adam_out; double* adam_pw; float lr, b1, b2;   // with tick0: publish this step's Adam scalars
   unsigned w1_magic;                        // ceil(2^32 / ldw1) for the W1 parking index arithmetic
+  // Fused replay sampling (first kernel of a fused iteration, FUSE1 only): the x rows are read straight from the replay
+  // ring (row = this sample's index, field offset ring_off floats) and `gblocks` extra blocks at the end of the grid do
+  // the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.
+  int ring_rows; int ring_off; int nt_blocks; int gblocks; GatherArgs ga;
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -324,6 +329,10 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
+  if (FUSE1 && p.gblocks && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: these blocks are the replay gather
+    gather_body(p.ga, blockIdx.x - p.nt_blocks, (unsigned)p.gblocks);
+    return;
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   const int mt = wave / KS, ks = wave % KS;
@@ -355,10 +364,16 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       const int f = t + 256 * u;
       w1r[u] = f < w1n ? ld4(Pn + p.oW1 + 4 * (long)f) : f4(0.f);
     }
+    const float* xrow = G.in + ni * p.in_ns + (long)mrow * p.ld_in;
+    if (p.ring_rows) {                                       // this sample's record in the replay ring
+      const int id = p.ga.ctl->inject_idx ? p.ga.idx[mrow]
+                                          : (int)philox_index(p.ga.ctl->seed, (unsigned)p.ga.ctl->sample_ctr, (unsigned)mrow, (unsigned)p.ga.ctl->rb_len);
+      xrow = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + p.ring_off;
+    }
 #pragma unroll
     for (int c1 = 0; c1 < C1; ++c1) {
       const int k = 16 * c1 + 4 * kq;
-      xv[c1] = k < p.K1 ? zero_beyond(ld4(G.in + ni * p.in_ns + (long)mrow * p.ld_in + k), k, p.K1) : f4(0.f);
+      xv[c1] = k < p.K1 ? zero_beyond(ld4(xrow + k), k, p.K1) : f4(0.f);
     }
   } else {
 #pragma unroll
@@ -764,6 +779,7 @@ struct ActorTail {
   int a4;
   float td3_std, td3_c, noise_std;
   int ctr_add;                           // the primary draw uses stream counter *ctr + ctr_add
+  int* tick;                             // optional counter bumped by (block 0, thread 0)
   // SAC, dual mode: a SECOND, gradient-free draw through the same head outputs (the temperature step's fresh sample,
   // agents/agent.py:297-299) sharing this kernel with the next actor update's sample: only its log-prob is kept
   int dual; int site_buf2; unsigned site_code2; float* eps2; float* logp2;
@@ -790,6 +806,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   const bool valid = b < p.B;
   const int nh = p.L.nh, T = (nh + 15) >> 4;     // head column tiles (<= 4)
   const float* Wh = p.P + p.L.Wh;
+  if (p.tick && blockIdx.x == 0 && t == 0) *p.tick += 1;
   STAMP(0);
   // loads first: my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3)
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
