@@ -185,6 +185,17 @@ def main():
         for _ in range(300):
             eng.predict(ob, True)
         out["predict_round_trip_us"] = (time.perf_counter() - tp) / 300 * 1e6
+        # rb.extend of one env step (num_envs = 4 rows, orchestrator.py:100-113): host pack + async H2D + length publish
+        rows = [np.zeros((4, w["o"]), np.float32), np.zeros((4, w["a"]), np.float32), np.zeros(4, np.float32),
+                np.zeros((4, w["o"]), np.float32), np.zeros(4, bool)]
+        for _ in range(700):   # (the HIP runtime grows its signal pools during the first few hundred async copies)
+            eng.rb_extend(*rows)
+        eng.sync()
+        tp = time.perf_counter()
+        for _ in range(300):
+            eng.rb_extend(*rows)
+        eng.sync()
+        out["rb_extend_call_us"] = (time.perf_counter() - tp) / 300 * 1e6
         if world == 1 and not args.no_baselines:
             # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
             sweep = {}

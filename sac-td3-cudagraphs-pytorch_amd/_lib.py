@@ -60,6 +60,13 @@ def load_library():
         raise EngineError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C sac-td3-cudagraphs-pytorch_amd/csrc`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If our library (linked against
+    # /opt/rocm's) were loaded first, a later `import torch` would bring a second runtime that finds no GPU.  Importing
+    # torch first makes the dynamic linker resolve our dependency to the copy already loaded.  (No torch: nothing to do.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     fp, u8p, i64p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.c_void_p
     sig = {

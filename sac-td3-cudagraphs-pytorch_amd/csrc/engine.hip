@@ -73,7 +73,7 @@ static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst)
 }
 
 enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_COUNT = 6 };
-static const int NSTAGE = 8;
+static const int NSTAGE = 32;
 
 struct sactd3_engine {
   sactd3_config cfg{};
@@ -107,7 +107,7 @@ struct sactd3_engine {
   float *part = nullptr, *part_s = nullptr;
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
   float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
-  float* h_stage[NSTAGE] = {}; hipEvent_t stage_ev[NSTAGE] = {}; int stage_next = 0;
+  float* h_stage[NSTAGE] = {}; int stage_next = 0, stage_used = 0;   // pinned staging slots of rb_extend
   float* h_batch = nullptr;                      // pinned [B][rec_f]
 
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
@@ -645,8 +645,6 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(halloc(e, &e->h_batch, B * e->rec_f));
   for (int i = 0; i < NSTAGE; ++i) {
     RCCHK(halloc(e, &e->h_stage[i], (size_t)e->stage_rows * e->rec_f));
-    HIPCHK(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
-    e->events.push_back(e->stage_ev[i]);
   }
 
   std::vector<float> hb(4 * e->a4, 0.f);
@@ -816,9 +814,11 @@ int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const
   const int64_t cap = e->cfg.rb_capacity;
   int done_rows = 0;
   while (done_rows < n) {
-    const int chunk = std::min(n - done_rows, e->stage_rows);
+    const int chunk = (int)std::min<int64_t>(std::min(n - done_rows, e->stage_rows), cap);
+    // staging slots are reused round-robin; one stream sync per lap of the ring of slots guarantees that the copy
+    // that last read a slot has completed (events / device-written flags cost more per call than this amortised sync)
+    if (++e->stage_used == NSTAGE) { HIPCHK(hipStreamSynchronize(e->stream)); e->stage_used = 1; }
     const int slot = e->stage_next; e->stage_next = (e->stage_next + 1) % NSTAGE;
-    HIPCHK(hipEventSynchronize(e->stage_ev[slot]));
     float* st = e->h_stage[slot];
     for (int i = 0; i < chunk; ++i) {
       const int r = done_rows + i;
@@ -833,10 +833,9 @@ int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const
       e->rb_len = std::min<int64_t>(cap, e->rb_len + run);
       left -= run; off += run;
     }
-    HIPCHK(hipEventRecord(e->stage_ev[slot], e->stream));
     done_rows += chunk;
   }
-  return publish_rb_state(e);
+  return n > 0 ? publish_rb_state(e) : 0;
 }
 
 int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EINVAL; }
