@@ -658,11 +658,31 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   const int ecol = k0 + (lane & 15);
   AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
   const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
+  STAMP(0);
   if (wave == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = n0 + 4 * (lane >> 4) + i;
       st[i] = (row < q.N && ecol < q.ldw) ? adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + ecol) : sv;
+    }
+  }
+  // k-tile-0 blocks also finalise the vector gradients of their 16 columns: request those operands and the
+  // optimiser state of the finalised elements now, so that the epilogue waits for nothing
+  const int fcol = t & 15, fpart = t >> 4, fn = n0 + fcol;         // (column, partial-group) of this thread
+  float fsum[3] = {0.f, 0.f, 0.f}, ssum = 0.f;
+  AdamState fst[3] = {sv, sv, sv}, bst = sv, sst = sv;
+  if (tk == 0) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      if (e < q.nfin && fn < q.N) {
+        for (int blk = fpart; blk < p.nblk; blk += 16)
+          fsum[e] += p.part[(((long)net * p.nblk + blk) * NSLOT + q.fin_slot[e]) * HID + fn];
+        if (t < 16) fst[e] = adam_fetch(p, nbase + q.fin_off[e] + fn);
+      }
+    if (q.b_off >= 0 && t < 16 && fn < q.N) bst = adam_fetch(p, nbase + q.b_off + fn);
+    if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
+      for (int blk = lane; blk < p.nblk; blk += 64) ssum += p.part_s[((long)net * p.nblk + blk) * 2];
+      if (lane == 0) sst = adam_fetch(p, nbase + q.fin_s_off);
     }
   }
   // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
@@ -681,6 +701,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       vx[u] = (m < p.M && k < Kr) ? zero_beyond(ld4(Xn + (long)m * q.ldx + k), k, q.K) : f4(0.f);
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u;
@@ -702,7 +723,9 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       for (int i = 0; i < 16; ++i) asum += Ys[(part * 16 + i) * YS + col];
     }
   }
+  STAMP(2);
   acc = splitk_reduce(red, acc, wave, lane);
+  STAMP(3);
   if (wave == 0 && ecol < q.ldw) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -711,47 +734,35 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
   }
   if (tk == 0) {
-    const int col = t & 15, part = t >> 4, n = n0 + col;     // (col, part) == (r, 4 wave + kq)
     if (q.b_off >= 0) {
-      const long off = nbase + q.b_off + n;
-      if (t < 16 && n < q.N) sv = adam_fetch(p, off);
-      cred[part * 17 + col] = asum;
+      cred[fpart * 17 + fcol] = asum;
       __syncthreads();
-      if (t < 16 && n < q.N) {
+      if (t < 16 && fn < q.N) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += cred[i * 17 + t];
-        adam_commit(p, off, s, sv, step, sq2);
+        adam_commit(p, nbase + q.b_off + fn, s, bst, step, sq2);
       }
     }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {            // 16 threads per column, blocks strided over them, all loads independent
+    for (int e = 0; e < 3; ++e) {            // 16 threads per column hold the partial sums requested at the top
       if (e >= q.nfin) break;
-      const long off = nbase + q.fin_off[e] + n;
-      if (t < 16 && n < q.N) sv = adam_fetch(p, off);
-      float s = 0.f;
-      if (n < q.N)
-        for (int blk = part; blk < p.nblk; blk += 16)
-          s += p.part[(((long)net * p.nblk + blk) * NSLOT + q.fin_slot[e]) * HID + n];
       __syncthreads();
-      cred[part * 17 + col] = s;
+      cred[fpart * 17 + fcol] = fsum[e];
       __syncthreads();
-      if (t < 16 && n < q.N) {
+      if (t < 16 && fn < q.N) {
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v += cred[i * 17 + t];
-        adam_commit(p, off, v, sv, step, sq2);
+        adam_commit(p, nbase + q.fin_off[e] + fn, v, fst[e], step, sq2);
       }
     }
     if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
-      const long off = nbase + q.fin_s_off;
-      if (lane == 0) sv = adam_fetch(p, off);
-      float s = 0.f;
-      for (int blk = lane; blk < p.nblk; blk += 64) s += p.part_s[((long)net * p.nblk + blk) * 2];
-      s = wave_sum(s);
-      if (lane == 0) adam_commit(p, off, s, sv, step, sq2);
+      const float s = wave_sum(ssum);
+      if (lane == 0) adam_commit(p, nbase + q.fin_s_off, s, sst, step, sq2);
     }
   }
+  STAMP(4);
   if (blockIdx.x == 0 && net == 0 && wave == 2) {
     if (p.loss_dst) {
       float s = 0.f;

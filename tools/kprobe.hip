@@ -47,10 +47,29 @@ int main() {
     const int rb = 64 / ks;
     const dim3 grid((B / rb) * 16, 1, nets);
     double us;
-    if (ks == 4) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 4>), grid, dim3(256), 0, s, h); }, 20, 50);
-    else if (ks == 2) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 2>), grid, dim3(256), 0, s, h); }, 20, 50);
-    else us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 1>), grid, dim3(256), 0, s, h); }, 20, 50);
+    if (ks == 4) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 4, 1>), grid, dim3(256), 0, s, h); }, 20, 50);
+    else if (ks == 2) us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 2, 1>), grid, dim3(256), 0, s, h); }, 20, 50);
+    else us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt<1, true, 1, 1>), grid, dim3(256), 0, s, h); }, 20, 50);
     char nm[64]; snprintf(nm, 64, "k_nt<1,fused,KS=%d> nets=%d", ks, nets); show(nm, us, 6);
+  }
+  {  // critic weight-gradient launch: dW2 (256 x 256) + dW1 (256 x 16), 2 nets, Adam on
+    float *G, *Mo, *Vo, *T, *adam, *part, *ps;
+    CK(hipMalloc(&G, 2 * 80000 * 4)); CK(hipMalloc(&Mo, 2 * 80000 * 4)); CK(hipMalloc(&Vo, 2 * 80000 * 4)); CK(hipMalloc(&T, 2 * 80000 * 4));
+    CK(hipMalloc(&adam, 16)); CK(hipMalloc(&part, 2 * 16 * NSLOT * 256 * 4)); CK(hipMalloc(&ps, 2 * 16 * 2 * 4));
+    CK(hipMemset(G, 0, 2 * 80000 * 4)); CK(hipMemset(Mo, 0, 2 * 80000 * 4)); CK(hipMemset(Vo, 0, 2 * 80000 * 4)); CK(hipMemset(T, 0, 2 * 80000 * 4));
+    float ha[2] = {1e-3f, 0.03f}; CK(hipMemcpy(adam, ha, 8, hipMemcpyHostToDevice)); CK(hipMemset(part, 0, 2 * 16 * NSLOT * 256 * 4)); CK(hipMemset(ps, 0, 2 * 16 * 2 * 4));
+    TnArgs g{}; g.nprob = 2; g.M = B; g.G = G; g.g_ns = 80000;
+    TnProb q0{}; q0.dY = Z2; q0.ldy = 256; q0.dy_ns = B * 256; q0.N = 256; q0.X = H; q0.ldx = 256; q0.x_ns = B * 256; q0.K = 256; q0.w_off = W2; q0.ldw = 256; q0.b_off = b2;
+    q0.nfin = 3; q0.fin_slot[0] = 0; q0.fin_off[0] = b2 + 256; q0.fin_slot[1] = 1; q0.fin_off[1] = b2 + 512; q0.fin_slot[2] = 2; q0.fin_off[2] = b2 + 768; q0.fin_s_off = b2 + 768 + 256; q0.tile0 = 0;
+    TnProb q1{}; q1.dY = Y; q1.ldy = 256; q1.dy_ns = B * 256; q1.N = 256; q1.X = X; q1.ldx = ldc; q1.x_ns = 0; q1.K = o + a; q1.w_off = W1; q1.ldw = 16; q1.b_off = b1;
+    q1.nfin = 2; q1.fin_slot[0] = 3; q1.fin_off[0] = g1; q1.fin_slot[1] = 4; q1.fin_off[1] = be1; q1.fin_s_off = -1; q1.tile0 = 256;
+    g.pr[0] = q0; g.pr[1] = q1; g.apply = 1; g.P = P; g.Mo = Mo; g.Vo = Vo; g.T = T; g.tau = 0.005f; g.adam = adam; g.b1 = 0.9f; g.b2 = 0.999f; g.eps = 1e-8f;
+    g.part = part; g.nblk = 16; g.part_s = ps; g.loss_part = ps; g.loss_n = 32; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.f / B; g.loss_dst = adam + 2;
+    double us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
+    show("k_tn critics (+Adam)", us, 5);
+    g.apply = 0;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
+    show("k_tn critics (grads only)", us, 5);
   }
   {
     NetLayout L{}; L.K = o; L.ld1 = 12; L.nh = 2 * a; L.W1 = 0; L.b1 = b1; L.g1 = g1; L.be1 = be1; L.W2 = W2; L.b2 = b2; L.g2 = b2 + 256; L.be2 = b2 + 512; L.Wh = b2 + 768; L.bh = L.Wh + 6 * 256;
