@@ -468,3 +468,42 @@ def test_actor_update_delay_other_than_two():
         _, _, tq = eng.get_adam_state(_lib.CRITICS)
         assert tq == 2 * (delay + 1) and ta == 2 * delay
         assert all(np.isfinite(v) for v in eng.read_metrics().values())
+
+
+@pytest.mark.parametrize("algo,o,a,B", [("sac", 64, 1, 48), ("sac", 65, 16, 33), ("sac", 3, 32, 64), ("td3", 48, 17, 80),
+                                         ("sac", 20, 5, 16), ("td3", 1, 1, 17)])
+def test_one_iteration_odd_dimensions(algo, o, a, B):
+    """Edges of the kernels' shape handling: fused first layer up to 64 inputs (1, 2 or 4 k-chunks) vs the wide path
+    from 65, head widths up to 64 outputs (4 MFMA column tiles), batch sizes that are not multiples of 16."""
+    bound = 0.7
+    hps = (Hps.td3 if algo == "td3" else Hps.sac)(batch_size=B)
+    torch.manual_seed(1)
+    ref = RefAgent(o, a, [-bound] * a, [bound] * a, hps)
+    randomize_ln(ref)
+    eng = P.Engine(P.Config.from_hps(hps, o, a, rb_capacity=512, max_envs=4, seed=1), [-bound] * a, [bound] * a)
+    push_params(eng, ref)
+    obs, act, rew, nobs, done = synth_transitions(B, o, a, bound, seed=51)
+    g = torch.Generator().manual_seed(52)
+    noise = {"critic": torch.randn(B, a, generator=g), "actor": [torch.randn(B, a, generator=g) for _ in range(2)],
+             "alpha": [torch.randn(B, a, generator=g) for _ in range(2)]}
+    want = {k: float(v) for k, v in ref.iteration(ref.to_batch(obs, act, rew, nobs, done), 0, noise).items()}
+    eng.load_batch(obs, act, rew, nobs, done)
+    eng.set_noise(_lib.SITE_CRITIC, noise["critic"])
+    eng.update_qnets()
+    for j in range(2):
+        eng.set_noise(_lib.SITE_ACTOR0, noise["actor"][j]); eng.set_noise(_lib.SITE_ALPHA0, noise["alpha"][j])
+        eng.update_actor()
+    eng.update_targ_nets(1)
+    got = eng.read_metrics()
+    for k, v in want.items():
+        np.testing.assert_allclose(got[k], v, rtol=3e-5, atol=3e-5, err_msg=k)
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics", max_bad_frac=5e-3)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=2e-2)
+    x = torch.randn(3, o, generator=g)
+    close(eng.predict(x, explore=False), ref.predict(x, explore=False), name="predict")
+    # and the fused iteration runs on these shapes too
+    o_, a_, r_, n_, d_ = [t.numpy() for t in synth_transitions(300, o, a, bound, seed=53)]
+    eng.rb_extend(o_, a_, r_, n_, d_)
+    for i in range(4):
+        eng.step(i % 3 == 0)
+    assert all(np.isfinite(v) for v in eng.read_metrics().values())
