@@ -204,6 +204,16 @@ def main():
                 sweep[str(bs)] = {"us": us_b, "GB/s": by / us_b * 1e-3}
             out["gather_batch_sweep"] = sweep
             eng.close()
+            # north_star's "replay-gather HBM GB/s as fraction of 8 TB/s": the same kernel on the Humanoid-v4 record
+            # (3136 B/row) out of a full 1M-row (3.1 GB, far beyond the 256 MB Infinity Cache) ring, 65 536 rows per launch
+            wh = WORKLOADS["humanoid_sac"]
+            eh = make_engine(wh, 0, local)
+            us_h, by_h = eh.time_gather_sweep(65536, 50)
+            out["replay_gather_hbm"] = {"record": "Humanoid-v4 (o=376, a=17), 1M-row ring", "rows_per_launch": 65536, "us": us_h,
+                                        "algo_bytes": by_h, "achieved": by_h / us_h * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": by_h / us_h * 1e-3 / HBM_PEAK_GBS,
+                                        "traffic": "417 MB per launch from FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_gather_humanoid_b65536_pmc.csv) = 1.03x algorithmic"}
+            eh.close()
             # the op sizes are tiny: torch's default of one thread per host core (128 here) is slower than a few threads,
             # so time 1 and 8 threads on a bounded sample each and report the faster one
             best = None
