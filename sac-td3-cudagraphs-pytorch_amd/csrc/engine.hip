@@ -84,7 +84,7 @@ struct sactd3_engine {
 
   int o = 0, a = 0, B = 0, ldc = 0, ldo = 0, a4 = 0, nh = 0, ldu = 0, rec_f = 0, rec4 = 0, cx = 0, cn = 0;
   int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
-  int nblk = 0;                // row-kernel blocks (16 rows each) for B rows
+  int nblk = 0, nblk4 = 0;     // row-kernel blocks for B rows: 16 rows each (MFMA-using tails) / 4 rows each (plain row kernels)
   int maxn = 0;                // rows accepted by predict
   int num_cus = 256;
   int stage_rows = 0;
@@ -104,7 +104,7 @@ struct sactd3_engine {
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
-  float *part = nullptr, *part_s = nullptr;
+  float *part = nullptr, *part_s = nullptr, *part_sa = nullptr;   // column partials; scalar partials of the critic / actor updates
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
   float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
   float* h_stage[NSTAGE] = {}; int stage_next = 0, stage_used = 0;   // pinned staging slots of rb_extend
@@ -222,7 +222,7 @@ static TnProb tn_prob(const float* dY, int ldy, long dy_ns, int N, const float* 
   q.w_off = w_off; q.ldw = ldw; q.b_off = b_off; q.nfin = 0; q.fin_s_off = -1;
   return q;
 }
-static void tn_fin(TnProb& q, int slot, int off) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin++] = off; }
+static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin] = off; q.fin_nblk[q.nfin++] = nblk; }
 
 // The two hidden layers of MLP trunks: z2 = relu(LN(x W1^T + b1)) W2^T + b2 for up to two groups of nets
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
@@ -332,8 +332,8 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
     t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
-    t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.nblk = e->nblk;
-    hipLaunchKernelGGL(k_critic_tail, dim3(e->nblk, 2), dim3(256), 0, s, t);
+    t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.pstride = e->nblk4;
+    hipLaunchKernelGGL(k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), 0, s, t);
     HIPCHK(hipGetLastError());
   }
   {  // dh1 = dz2 W2
@@ -346,8 +346,8 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     LnBwd l{};
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = ln;
-    l.dz = e->c_dz1; l.part = e->part; l.nblk = e->nblk;
-    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 2), dim3(256), 0, s, l);
+    l.dz = e->c_dz1; l.part = e->part; l.pstride = e->nblk4;
+    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, 2), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {  // every critic gradient + the Adam step (+ Polyak) in one launch:
@@ -355,14 +355,14 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     TnArgs g{};
     g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
     g.pr[0] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
-    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2); tn_fin(g.pr[0], 1, e->Lc.be2); }
-    tn_fin(g.pr[0], 2, e->Lc.Wh); g.pr[0].fin_s_off = e->Lc.bh;
+    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, e->nblk); tn_fin(g.pr[0], 1, e->Lc.be2, e->nblk); }
+    tn_fin(g.pr[0], 2, e->Lc.Wh, e->nblk); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = e->nblk;
     g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, e->X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
-    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1); tn_fin(g.pr[1], 4, e->Lc.be1); }
-    g.part = e->part; g.nblk = e->nblk; g.part_s = e->part_s;
+    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1, e->nblk); tn_fin(g.pr[1], 4, e->Lc.be1, e->nblk); }
+    g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
-    g.loss_part = e->part_s; g.loss_n = 2 * e->nblk; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
+    g.loss_part = e->part_s; g.loss_n = 2 * e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;   // unused tail entries stay 0
     g.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS]; g.tick = &e->ctl->noise_ctr;
     RCCHK(launch_tn(e, s, g, 2));
   }
@@ -392,8 +392,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
-    t.B = B; t.ln = ln; t.sac = !td3; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_s; t.nblk = e->nblk;
-    hipLaunchKernelGGL(k_actorq_tail, dim3(e->nblk), dim3(256), 0, s, t);
+    t.B = B; t.ln = ln; t.sac = !td3; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_sa;
+    hipLaunchKernelGGL(k_actorq_tail<4>, dim3(e->nblk4), dim3(64), 0, s, t);
     HIPCHK(hipGetLastError());
   }
   {
@@ -406,10 +406,10 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     LnBwd l{};
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = 0;
-    l.dz = e->c_dz1; l.part = e->part; l.nblk = e->nblk;
+    l.dz = e->c_dz1; l.part = e->part; l.pstride = e->nblk4;
     // fused: dA_i = dz1_i W1_i[:, o:o+a]  (gradient of Q_i with respect to the action)
     l.W1 = e->Pc + e->Lc.W1; l.ldw1 = e->Lc.ld1; l.k_off = e->o; l.na = e->a; l.dA = e->dA; l.ldA = e->a4;
-    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, nq), dim3(256), 0, s, l);
+    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, nq), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {
@@ -417,7 +417,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     h.dA = e->dA; h.dA_ns = (long)B * e->a4; h.ldA = e->a4; h.nq = nq; h.tg = e->a_tg; h.a4 = e->a4; h.eps = e->eps[sb_a];
     h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.xh2 = e->a_xh2; h.rstd2 = e->a_rs2; h.h2 = e->a_h2;
     h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
-    h.part = e->part; h.nblk = e->nblk;
+    h.part = e->part;
     hipLaunchKernelGGL(k_actor_head_bwd, dim3(e->nblk), dim3(256), 0, s, h);
     HIPCHK(hipGetLastError());
   }
@@ -429,8 +429,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   {
     LnBwd l{};
     l.dh = e->a_dh1; l.xh = e->a_xh1; l.h = e->a_h1; l.rstd = e->a_rs1; l.gamma = e->Pa + e->La.g1;
-    l.B = B; l.ln = ln; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.nblk = e->nblk;
-    hipLaunchKernelGGL(k_ln_bwd, dim3(e->nblk, 1), dim3(256), 0, s, l);
+    l.B = B; l.ln = ln; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.pstride = e->nblk4;
+    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, 1), dim3(256), 0, s, l);
     HIPCHK(hipGetLastError());
   }
   {  // every actor gradient (+ Adam unless clip_grad_norm_ needs the global norm first) in one launch:
@@ -439,13 +439,13 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
     g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
     g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
-    if (ln) { tn_fin(g.pr[1], 0, e->La.g2); tn_fin(g.pr[1], 1, e->La.be2); }
+    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, e->nblk); tn_fin(g.pr[1], 1, e->La.be2, e->nblk); }
     g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, e->X, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
-    if (ln) { tn_fin(g.pr[2], 3, e->La.g1); tn_fin(g.pr[2], 4, e->La.be1); }
-    g.part = e->part; g.nblk = e->nblk; g.part_s = e->part_s;
+    if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
+    g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = nullptr; g.adam = e->ctl->adam_a;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
-    g.loss_part = e->part_s; g.loss_n = e->nblk; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
+    g.loss_part = e->part_sa; g.loss_n = e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
     g.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS]; g.tick = (td3 && !clip) ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_tn(e, s, g, 1));
   }
@@ -608,7 +608,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if ((long long)e->B * e->rec4 >= (1ll << 31)) return e->fail(SACTD3_EINVAL, "batch_size x record size too large");
   e->La = make_layout(e->o, e->nh); e->Lc = make_layout(e->o + e->a, 1);
   e->nq_actor = td3 ? 1 : 2;
-  e->nblk = (e->B + 15) / 16;
+  e->nblk = (e->B + 15) / 16; e->nblk4 = (e->B + 3) / 4;
   e->maxn = c.max_envs;
   e->stage_rows = std::max(c.max_envs, 256);
   const size_t B = e->B, BH = B * HID;
@@ -638,7 +638,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->t_z1, 2 * BH)); RCCHK(dalloc(e, &e->t_z2, 2 * BH));
   RCCHK(dalloc(e, &e->q, 2 * B)); RCCHK(dalloc(e, &e->qt, 2 * B)); RCCHK(dalloc(e, &e->y, B)); RCCHK(dalloc(e, &e->q_pi, 2 * B));
   RCCHK(dalloc(e, &e->dA, 2 * B * e->a4));
-  RCCHK(dalloc(e, &e->part, 2 * (size_t)e->nblk * NSLOT * HID)); RCCHK(dalloc(e, &e->part_s, 2 * (size_t)e->nblk * 2));
+  RCCHK(dalloc(e, &e->part, 2 * (size_t)e->nblk4 * NSLOT * HID)); RCCHK(dalloc(e, &e->part_s, 2 * (size_t)e->nblk4 * 2)); RCCHK(dalloc(e, &e->part_sa, (size_t)e->nblk4 * 2));
   RCCHK(dalloc(e, &e->p_x, (size_t)e->maxn * e->ldo)); RCCHK(dalloc(e, &e->p_z1, (size_t)e->maxn * HID));
   RCCHK(dalloc(e, &e->p_z2, (size_t)e->maxn * HID)); RCCHK(dalloc(e, &e->p_act, (size_t)e->maxn * e->a4));
   RCCHK(halloc(e, &e->h_obs, (size_t)e->maxn * e->ldo)); RCCHK(halloc(e, &e->h_act, (size_t)e->maxn * e->a4));

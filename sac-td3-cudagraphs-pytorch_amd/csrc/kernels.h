@@ -171,18 +171,19 @@ __device__ __forceinline__ Row16 ln_bwd(const Row16& dy, const Row16& xh, float 
   for (int q = 0; q < 4; ++q) dz.v[q] = (dxh.v[q] - f4(m1) - xh.v[q] * m2) * rstd;
   return dz;
 }
-// Column sums over the 16 rows of a block for `nslots` quantities; cs = __shared__ float[nslots][16][HID].
-// Thread t ends up writing column t of every slot to dst[slot][t].  Contains barriers: all 256 threads call it.
+// Column sums over the RPB rows of a block (blockDim = 16 RPB) for `nslots` quantities; cs = __shared__ float[nslots][RPB][HID].
+// Column c of every slot is written to dst[slot][c].  Contains a barrier: every thread of the block calls it.
+template <int RPB>
 __device__ __forceinline__ void block_colsum(float* cs, const Row16* vals, int nslots, int row, int sub, float* dst) {
-  for (int s = 0; s < nslots; ++s) row_st(cs + (s * 16 + row) * HID, sub, vals[s]);
+  for (int s = 0; s < nslots; ++s) row_st(cs + (s * RPB + row) * HID, sub, vals[s]);
   __syncthreads();
-  const int t = threadIdx.x;
-  for (int s = 0; s < nslots; ++s) {
-    float a = 0.f;
+  for (int c = threadIdx.x; c < HID; c += 16 * RPB)
+    for (int s = 0; s < nslots; ++s) {
+      float a = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a += cs[(s * 16 + r) * HID + t];
-    dst[s * HID + t] = a;
-  }
+      for (int r = 0; r < RPB; ++r) a += cs[(s * RPB + r) * HID + c];
+      dst[s * HID + c] = a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ replay
@@ -604,8 +605,8 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   const float* X; int ldx; long x_ns; int K;
   int w_off, ldw;                        // where the weight block sits inside a net's parameter / gradient block
   int b_off;                             // its bias (gradient = column sums of dY), -1: none
-  int nfin; int fin_slot[3]; int fin_off[3];   // vectors that come from row-kernel partials: part[net][blk][slot][n] summed over blk
-  int fin_s_off;                         // scalar from part_s[net][blk][0] summed over blk (critic head bias), -1: none
+  int nfin; int fin_slot[3]; int fin_off[3]; int fin_nblk[3];   // vectors from row-kernel partials: part[net][blk][slot][n] summed over blk < fin_nblk
+  int fin_s_off; int fin_s_nblk;         // scalar from part_s[net][blk][0] summed over blk (critic head bias), -1: none
   int tile0;                             // first blockIdx.x of this problem
 };
 struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
@@ -616,7 +617,7 @@ struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16
   int apply; float* P; float* Mo; float* Vo; float* T; float tau;
   const float* adam;                     // [0] lr / (1 - b1^t), [1] sqrt(1 - b2^t), published by the first kernel of the update
   float b1, b2, eps;
-  const float* part; int nblk; const float* part_s;
+  const float* part; int pstride; const float* part_s;   // pstride = partial blocks allocated per net
   // extras done once by block 0 / net 0: loss finalisation and a counter tick
   const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
 };
@@ -675,13 +676,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
 #pragma unroll
     for (int e = 0; e < 3; ++e)
       if (e < q.nfin && fn < q.N) {
-        for (int blk = fpart; blk < p.nblk; blk += 16)
-          fsum[e] += p.part[(((long)net * p.nblk + blk) * NSLOT + q.fin_slot[e]) * HID + fn];
+        for (int blk = fpart; blk < q.fin_nblk[e]; blk += 16)
+          fsum[e] += p.part[(((long)net * p.pstride + blk) * NSLOT + q.fin_slot[e]) * HID + fn];
         if (t < 16) fst[e] = adam_fetch(p, nbase + q.fin_off[e] + fn);
       }
     if (q.b_off >= 0 && t < 16 && fn < q.N) bst = adam_fetch(p, nbase + q.b_off + fn);
     if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
-      for (int blk = lane; blk < p.nblk; blk += 64) ssum += p.part_s[((long)net * p.nblk + blk) * 2];
+      for (int blk = lane; blk < q.fin_s_nblk; blk += 64) ssum += p.part_s[((long)net * p.pstride + blk) * 2];
       if (lane == 0) sst = adam_fetch(p, nbase + q.fin_s_off);
     }
   }
@@ -937,14 +938,16 @@ struct CriticTail {
   int B, ln, sac, bcq; float gamma;
   float* qt; float* y; float* q;         // [2][B], [B], [2][B]
   float* dz2;                            // [2][B][HID]
-  float* part; float* part_s; int nblk;  // [2][nblk][NSLOT][HID], [2][nblk][2] (sum dq, sum sq-err)
+  float* part; float* part_s; int pstride;  // [2][pstride][NSLOT][HID], [2][pstride][2] (sum dq, sum sq-err)
 };
 
-__global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
-  __shared__ __attribute__((aligned(16))) float cs[3 * 16 * HID];
-  __shared__ float sc[16][2];
+// RPB rows per block (blockDim = 16 RPB): fewer rows per block = fewer bytes fetched per CU for these fetch-bound kernels
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_critic_tail(CriticTail p) {
+  __shared__ __attribute__((aligned(16))) float cs[3 * RPB * HID];
+  __shared__ float sc[RPB][2];
   const int t = threadIdx.x, row = t >> 4, sub = t & 15, net = blockIdx.y;
-  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const float* Pn = p.P + net * p.p_ns;
   STAMP(0);
@@ -998,12 +1001,12 @@ __global__ __launch_bounds__(256) void k_critic_tail(CriticTail p) {
   }
   if (sub == 0) { sc[row][0] = dq; sc[row][1] = err * err; }
   STAMP(2);
-  const long blk = (long)net * p.nblk + blockIdx.x;
-  block_colsum(cs, vals, 3, row, sub, p.part + blk * NSLOT * HID);   // (has the barrier that publishes sc)
+  const long blk = (long)net * p.pstride + blockIdx.x;
+  block_colsum<RPB>(cs, vals, 3, row, sub, p.part + blk * NSLOT * HID);   // (has the barrier that publishes sc)
   if (t < 2) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += sc[i][t];
+    for (int i = 0; i < RPB; ++i) s += sc[i][t];
     p.part_s[blk * 2 + t] = s;
   }
   STAMP(3);
@@ -1015,13 +1018,14 @@ struct ActorQTail {
   const float* logp; const float* log_alpha;
   int B, ln, sac;
   float* q; float* dz2;                  // [nq][B], [nq][B][HID]
-  float* part_s; int nblk;               // [nblk][2]: loss partial in [.][1]
+  float* part_s;                         // [blocks][2]: loss partial in [.][1]
 };
 
-__global__ __launch_bounds__(256) void k_actorq_tail(ActorQTail p) {
-  __shared__ float sc[16];
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actorq_tail(ActorQTail p) {
+  __shared__ float sc[RPB];
   const int t = threadIdx.x, row = t >> 4, sub = t & 15;
-  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const int nq = p.sac ? 2 : 1;
   Row16 z[2], w[2], g[2], be[2], xh[2], y[2];
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_actorq_tail(ActorQTail p) {
   if (t == 0) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += sc[i];
+    for (int i = 0; i < RPB; ++i) s += sc[i];
     p.part_s[blockIdx.x * 2 + 1] = s;
   }
 }
@@ -1077,17 +1081,18 @@ struct LnBwd {               // dz = LNbwd(relu'(.) * dh) for hidden layer 1; op
   const float* gamma; long p_ns;
   int B, ln, want_part;
   float* dz;
-  float* part; int nblk;
-  // optional fused input gradient of a slice of layer 1: dA[net][b][0:na] = dz[b][:] . W1[:, k_off : k_off + na]
+  float* part; int pstride;
+  // optional fused input gradient of a slice of layer 1 (RPB == 16 only): dA[net][b][0:na] = dz[b][:] . W1[:, k_off : k_off + na]
   // (the dQ/da path of the actor update, agents/agent.py:272-283; na <= 32, not combined with want_part)
   const float* W1; int ldw1, k_off, na; float* dA; int ldA;
 };
 
-__global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
-  __shared__ __attribute__((aligned(16))) float cs[2 * 16 * HID];
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_ln_bwd(LnBwd p) {
+  __shared__ __attribute__((aligned(16))) float cs[2 * RPB * HID];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, row = t >> 4, sub = t & 15, net = blockIdx.y;
   const int r = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const long ro = ((long)net * p.B + bc) * HID;
   const Row16 dh = row_ld(p.dh + ro, sub), hh = row_ld(p.h + ro, sub), xh = row_ld(p.xh + ro, sub);
@@ -1095,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
   if (p.ln) g = row_ld(p.gamma + net * p.p_ns, sub);
   const float rstd = p.ln ? p.rstd[(long)net * p.B + bc] : 1.f;
   // B operand of the fused slice product, requested up front: W1[n = 16 (4 wave + ci) + 4 kq + jj][k_off + 16 tt + r]
-  const int T = p.dA ? (p.na + 15) >> 4 : 0;
+  const int T = (RPB == 16 && p.dA) ? (p.na + 15) >> 4 : 0;
   float4 wf[2][4];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -1115,8 +1120,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LnBwd p) {
   if (p.want_part) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
-    block_colsum(cs, vals, 2, row, sub, p.part + (((long)net * p.nblk + blockIdx.x) * NSLOT + 3) * HID);   // slots 3, 4
-  } else if (p.dA) {
+    block_colsum<RPB>(cs, vals, 2, row, sub, p.part + (((long)net * p.pstride + blockIdx.x) * NSLOT + 3) * HID);   // slots 3, 4
+  } else if (RPB == 16 && p.dA) {
     float* Dz = cs;                      // [16][AS]
     float* Up = cs + 16 * AS;            // [4 waves][16 rows][32]
     row_st(Dz + row * AS, sub, dz);
@@ -1150,7 +1155,7 @@ struct ActorHeadBwd {
   int B, a, ln, sac;
   float* du; int ldu;                    // [B][ldu] grad wrt head outputs
   float* dz2;                            // [B][HID]
-  float* part; int nblk;                 // [nblk][NSLOT][HID]
+  float* part;                           // [blocks][NSLOT][HID]
 };
 
 __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
@@ -1231,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
   if (valid) row_st(p.dz2 + (long)b * HID, sub, dz);
 #pragma unroll
   for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
-  block_colsum(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
+  block_colsum<16>(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
 }
 
 // ------------------------------------------------------------------------------------------------ optimiser

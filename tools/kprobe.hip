@@ -60,11 +60,11 @@ int main() {
     float ha[2] = {1e-3f, 0.03f}; CK(hipMemcpy(adam, ha, 8, hipMemcpyHostToDevice)); CK(hipMemset(part, 0, 2 * 16 * NSLOT * 256 * 4)); CK(hipMemset(ps, 0, 2 * 16 * 2 * 4));
     TnArgs g{}; g.nprob = 2; g.M = B; g.G = G; g.g_ns = 80000;
     TnProb q0{}; q0.dY = Z2; q0.ldy = 256; q0.dy_ns = B * 256; q0.N = 256; q0.X = H; q0.ldx = 256; q0.x_ns = B * 256; q0.K = 256; q0.w_off = W2; q0.ldw = 256; q0.b_off = b2;
-    q0.nfin = 3; q0.fin_slot[0] = 0; q0.fin_off[0] = b2 + 256; q0.fin_slot[1] = 1; q0.fin_off[1] = b2 + 512; q0.fin_slot[2] = 2; q0.fin_off[2] = b2 + 768; q0.fin_s_off = b2 + 768 + 256; q0.tile0 = 0;
+    q0.nfin = 3; q0.fin_slot[0] = 0; q0.fin_off[0] = b2 + 256; q0.fin_slot[1] = 1; q0.fin_off[1] = b2 + 512; q0.fin_slot[2] = 2; q0.fin_off[2] = b2 + 768; q0.fin_s_off = b2 + 768 + 256; q0.fin_s_nblk = 16; q0.fin_nblk[0] = q0.fin_nblk[1] = q0.fin_nblk[2] = 16; q0.tile0 = 0;
     TnProb q1{}; q1.dY = Y; q1.ldy = 256; q1.dy_ns = B * 256; q1.N = 256; q1.X = X; q1.ldx = ldc; q1.x_ns = 0; q1.K = o + a; q1.w_off = W1; q1.ldw = 16; q1.b_off = b1;
-    q1.nfin = 2; q1.fin_slot[0] = 3; q1.fin_off[0] = g1; q1.fin_slot[1] = 4; q1.fin_off[1] = be1; q1.fin_s_off = -1; q1.tile0 = 256;
+    q1.nfin = 2; q1.fin_slot[0] = 3; q1.fin_off[0] = g1; q1.fin_slot[1] = 4; q1.fin_off[1] = be1; q1.fin_s_off = -1; q1.fin_nblk[0] = q1.fin_nblk[1] = 16; q1.tile0 = 256;
     g.pr[0] = q0; g.pr[1] = q1; g.apply = 1; g.P = P; g.Mo = Mo; g.Vo = Vo; g.T = T; g.tau = 0.005f; g.adam = adam; g.b1 = 0.9f; g.b2 = 0.999f; g.eps = 1e-8f;
-    g.part = part; g.nblk = 16; g.part_s = ps; g.loss_part = ps; g.loss_n = 32; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.f / B; g.loss_dst = adam + 2;
+    g.part = part; g.pstride = 16; g.part_s = ps; g.loss_part = ps; g.loss_n = 32; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.f / B; g.loss_dst = adam + 2;
     double us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
     show("k_tn critics (+Adam)", us, 5);
     g.apply = 0;
@@ -81,11 +81,11 @@ int main() {
     t.dst = X; t.ldd = ldc; t.dst_off = o; t.logp = logp; t.h2 = H; t.xh2 = XH; t.rstd2 = RS; t.tg = tg; t.a4 = 4;
     double us = graph_us(s, [&] { hipLaunchKernelGGL(k_actor_tail, dim3(B / 16), dim3(256), 0, s, t); }, 20, 50);
     show("k_actor_tail(train)", us, 6);
-    float *q3, *dz, *part, *ps; CK(hipMalloc(&q3, 8 * B * 4)); CK(hipMalloc(&dz, 2 * B * 256 * 4)); CK(hipMalloc(&part, 2 * 16 * 4 * 256 * 4)); CK(hipMalloc(&ps, 2 * 16 * 2 * 4));
+    float *q3, *dz, *part, *ps; CK(hipMalloc(&q3, 8 * B * 4)); CK(hipMalloc(&dz, 2 * B * 256 * 4)); CK(hipMalloc(&part, 2 * 64 * NSLOT * 256 * 4)); CK(hipMalloc(&ps, 2 * 64 * 2 * 4));
     NetLayout Lc = L; Lc.nh = 1;
     CriticTail c{}; c.z2t = Z2; c.z2 = Y; c.PT = P; c.P = P; c.p_ns = 80000; c.L = Lc; c.rew = logp; c.done = logp; c.logp_next = logp; c.log_alpha = sc + 4;
-    c.B = B; c.ln = 1; c.sac = 1; c.bcq = 0; c.gamma = 0.99f; c.qt = q3; c.y = q3 + 2 * B; c.q = q3 + 4 * B; c.dz2 = dz; c.part = part; c.part_s = ps; c.nblk = 16;
-    us = graph_us(s, [&] { hipLaunchKernelGGL(k_critic_tail, dim3(16, 2), dim3(256), 0, s, c); }, 20, 50);
+    c.B = B; c.ln = 1; c.sac = 1; c.bcq = 0; c.gamma = 0.99f; c.qt = q3; c.y = q3 + 2 * B; c.q = q3 + 4 * B; c.dz2 = dz; c.part = part; c.part_s = ps; c.pstride = 64;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_critic_tail<4>, dim3(64, 2), dim3(64), 0, s, c); }, 20, 50);
     show("k_critic_tail", us, 4);
   }
   return 0;
