@@ -332,7 +332,7 @@ def test_graph_replay_equals_eager_launches(algo, env):
     assert outs[0][4] > 0 and outs[1][4] == 0
 
 
-@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah")])
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah"), ("sac", "humanoid")])
 def test_fused_step_equals_api_sequence(algo, env):
     """sactd3_step (one graph per iteration) == rb_sample + update_qnets + 2x update_actor + update_targ_nets."""
     B = 64
