@@ -48,3 +48,45 @@ def aggregate(dist, local_units: float, local_seconds: float, device=None) -> Tu
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()), float(t.item())
+
+
+class SharedReplay:
+    """Optional shared-replay variant (BASELINE.json north_star; not in the reference): every rank appends the new
+    transitions of ALL ranks, so each GPU's ring holds every seed's data.  The exchange is one all-gather per key
+    and env step (num_envs x ~100 B per rank: latency-bound; RCCL over xGMI when the backend is nccl) -- the only
+    collective on the data path, and only in this variant.  Wraps any buffer with the reference's `extend(td)` /
+    `sample(B)` / `len()`; rows are appended in rank order, so all rings stay identical."""
+
+    KEYS = ("observations", "next_observations", "actions", "rewards", "terminations", "dones")
+
+    def __init__(self, dist, rb, device=None):
+        self.dist, self.rb, self.device = dist, rb, device
+
+    def extend(self, td) -> None:
+        import numpy as np
+        import torch
+        if self.dist is None:
+            return self.rb.extend(td)
+        world = self.dist.get_world_size()
+        out = {}
+        for k in self.KEYS:
+            if k not in td:
+                continue
+            x = td[k]
+            x = x.detach() if hasattr(x, "detach") else torch.as_tensor(np.asarray(x))
+            x = x.to(torch.float32).reshape(x.shape[0], -1).contiguous()
+            if self.device is not None:
+                x = x.to(self.device)
+            buf = [torch.empty_like(x) for _ in range(world)]
+            self.dist.all_gather(buf, x)
+            out[k] = torch.cat(buf, 0).cpu().numpy()
+        for k in ("terminations", "dones"):
+            if k in out:
+                out[k] = out[k] != 0
+        self.rb.extend(out)
+
+    def sample(self, batch_size):
+        return self.rb.sample(batch_size)
+
+    def __len__(self):
+        return len(self.rb)

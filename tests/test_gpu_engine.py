@@ -507,3 +507,35 @@ def test_one_iteration_odd_dimensions(algo, o, a, B):
     for i in range(4):
         eng.step(i % 3 == 0)
     assert all(np.isfinite(v) for v in eng.read_metrics().values())
+
+
+def test_error_paths_return_codes_not_crashes():
+    """The C ABI reports bad calls through error codes / messages (include/sactd3.h conventions)."""
+    import ctypes as C
+    lib = P.load_library()
+    cc = P.Config(ob_dim=11, ac_dim=3, batch_size=32, rb_capacity=128).to_c()
+    lo, hi = (C.c_float * 3)(-1, -1, -1), (C.c_float * 3)(1, 1, 1)
+    h = C.c_void_p()
+    for field, bad in (("abi_version", 99), ("ob_dim", 0), ("ac_dim", 33), ("batch_size", 0), ("device_id", 64), ("crit_targ_update_freq", 0)):
+        c2 = P.Config(ob_dim=11, ac_dim=3, batch_size=32, rb_capacity=128).to_c()
+        setattr(c2, field, bad)
+        assert lib.sactd3_create(C.byref(c2), lo, hi, C.byref(h)) < 0 and not h.value, field
+        assert lib.sactd3_last_error(None)
+    assert lib.sactd3_create(C.byref(cc), None, hi, C.byref(h)) < 0
+    eng = P.Engine(P.Config(ob_dim=11, ac_dim=3, batch_size=32, rb_capacity=128), [-1] * 3, [1] * 3)
+    with pytest.raises(ValueError):
+        eng.set_params(_lib.ACTOR, np.zeros(5, np.float32))                 # wrong length caught before the call
+    assert lib.sactd3_get_params(eng._h, 17, (C.c_float * 4)()) < 0          # unknown parameter set
+    with pytest.raises(P.EngineError):
+        eng.load_batch(np.zeros((8, 11)), np.zeros((8, 3)), np.zeros(8), np.zeros((8, 11)), np.zeros(8))   # n != batch_size
+    with pytest.raises(P.EngineError):
+        eng.set_noise(_lib.SITE_CRITIC, np.zeros((64, 3), np.float32))        # more rows than a batch
+    with pytest.raises(P.EngineError):
+        eng.debug_read("no_such_buffer")
+    with pytest.raises(P.EngineError):
+        eng.rb_fill_synthetic(129)                                           # beyond capacity
+    assert lib.sactd3_graph_kernel_count(eng._h, 9) < 0 and lib.sactd3_sync(None) < 0
+    # the engine is still usable afterwards
+    eng.rb_fill_synthetic(100)
+    eng.step(True)
+    assert all(np.isfinite(v) for v in eng.read_metrics().values())

@@ -41,3 +41,45 @@ def test_two_rank_seed_sharding_and_aggregation():
 def test_single_process_is_the_identity():
     assert launcher.shard_seeds(3, 1, 0, first_seed=5) == [5, 6, 7]
     assert launcher.aggregate(None, 10.0, 2.0) == (10.0, 2.0)
+
+
+class _ListRB:
+    def __init__(self):
+        self.rows = []
+
+    def extend(self, td):
+        import numpy as np
+        n = len(td["observations"])
+        for i in range(n):
+            self.rows.append({k: np.array(v[i]) for k, v in td.items()})
+
+    def __len__(self):
+        return len(self.rows)
+
+
+def _shared_worker(rank, world, port, q):
+    import numpy as np
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = launcher.init_process_group("gloo")
+    rb = launcher.SharedReplay(dist, _ListRB())
+    for step in range(3):   # each rank contributes 2 rows per step, tagged with its rank and the step
+        base = 100.0 * rank + 10.0 * step
+        rb.extend({"observations": np.full((2, 3), base, np.float32), "next_observations": np.full((2, 3), base + 1, np.float32),
+                   "actions": np.full((2, 1), base + 2, np.float32), "rewards": np.full((2, 1), base + 3, np.float32),
+                   "terminations": np.array([[rank == 1], [False]]), "dones": np.array([[rank == 1], [False]])})
+    q.put((rank, len(rb), [float(r["observations"][0]) for r in rb.rb.rows], [bool(r["dones"].any()) for r in rb.rb.rows]))
+    dist.destroy_process_group()
+
+
+def test_shared_replay_variant_keeps_all_rings_identical():
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, n0, obs0, d0), (_, n1, obs1, d1) = out
+    assert n0 == n1 == 12 and obs0 == obs1 and d0 == d1                 # every ring holds every rank's rows, same order
+    assert obs0[:4] == [0.0, 0.0, 100.0, 100.0] and obs0[4:8] == [10.0, 10.0, 110.0, 110.0]
+    assert d0[:4] == [False, False, True, False]                        # rank 1's termination flag travelled with its row
