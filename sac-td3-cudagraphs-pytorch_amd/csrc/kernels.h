@@ -353,11 +353,6 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   STAMP(0);
   // ---- 1. every global load, coalesced where the data is shared by the block
   float4 w2r[4], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {                              // W tile: 16 rows x 256 floats, one row per wave-instruction
-    const int i = t + 256 * u, row = i >> 6, c4 = i & 63, n = min(n0 + row, p.N - 1);
-    w2r[u] = ld4(Pn + p.oW + (long)n * p.ldw + 4 * c4);
-  }
   const int w1n = FUSE1 ? (HID * p.ldw1) >> 2 : 0;           // float4s of W1 (rows are 16-byte multiples, contiguous)
   if (FUSE1) {
 #pragma unroll
@@ -384,6 +379,13 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     const int which = t >> 6, c4 = t & 63;
     const int off = which == 0 ? p.oB1 : (which == 1 ? p.oG : p.oBe);
     if ((which == 0 && FUSE1) || (which != 0 && PRO == 1)) vr = ld4(Pn + off + 4 * c4);
+  }
+  // the second layer's W tile is requested LAST (loads return in order): the first layer and the row statistics run
+  // while it is still in flight
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {                              // 16 rows x 256 floats, one row per wave-instruction
+    const int i = t + 256 * u, row = i >> 6, c4 = i & 63, n = min(n0 + row, p.N - 1);
+    w2r[u] = ld4(Pn + p.oW + (long)n * p.ldw + 4 * c4);
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- 2. park the shared operands in LDS (W1 first: the first layer only needs W1, x, b1)
