@@ -72,6 +72,7 @@ static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst)
   memcpy(dst, src + L.bh, sizeof(float) * L.nh);
 }
 
+static const int BIG_BATCH = 1024;   // from here on the hidden layers run as 64 x 64-tiled GEMMs + a LayerNorm row kernel
 enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_COUNT = 6 };
 static const int NSTAGE = 32;
 
@@ -104,6 +105,7 @@ struct sactd3_engine {
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
+  float* s_h1 = nullptr;         // large-batch path: layer-1 activations of nets whose caller keeps no copy ([4][B][256])
   float *part = nullptr, *part_s = nullptr, *part_sa = nullptr;   // column partials; scalar partials of the critic / actor updates
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
   float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
@@ -239,6 +241,33 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.g[i].P = grp[i].P; h.g[i].Y = grp[i].z2; h.g[i].xh_out = grp[i].xh; h.g[i].h_out = grp[i].h; h.g[i].rstd_out = grp[i].rstd;
   }
   const int nets = ngrp * npg;
+  // MFMA-bound sizes with enough 64 x 64 tiles to fill the chip: tiled GEMM -> LayerNorm row kernel -> tiled GEMM
+  if (M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4) {
+    NtArgs g{};
+    g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
+    g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
+    for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
+    g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
+    const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64)), 1, (unsigned)nets);
+    hipLaunchKernelGGL(k_nt64, grid, dim3(256), 0, s, g);
+    HIPCHK(hipGetLastError());
+    LnFwd l{};
+    l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
+    for (int i = 0; i < ngrp; ++i) {
+      l.P[i] = grp[i].P; l.zin[i] = grp[i].z1;
+      l.h[i] = grp[i].h ? grp[i].h : e->s_h1 + (size_t)i * npg * M * HID;
+      l.xh[i] = grp[i].xh; l.rstd[i] = grp[i].rstd;
+    }
+    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((M + 15) / 16), (unsigned)nets), dim3(256), 0, s, l);
+    HIPCHK(hipGetLastError());
+    NtArgs h2{};
+    h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
+    h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
+    for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
+    hipLaunchKernelGGL(k_nt64, grid, dim3(256), 0, s, h2);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (K <= 64) {
     for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].x;
     h.ld_in = ldx; h.in_ns = 0; h.K1 = K; h.oW1 = L.W1; h.ldw1 = L.ld1; h.oB1 = L.b1;
@@ -311,7 +340,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   const float* Pact = td3 ? e->Ta : e->Pa;
   {
     const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
-    const bool in_kernel_gather = fused_sample && e->o <= 64;
+    const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
     tk.fuse_gather = in_kernel_gather;
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
@@ -502,7 +531,7 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 // orchestrator.py:337-352 as one sequence
 static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
-  if (e->o > 64) RCCHK(enqueue_gather(e, s, e->ring, -1));   // narrow observations: the gather is inside the first trunk kernel
+  if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
   RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr));
@@ -638,6 +667,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->t_z1, 2 * BH)); RCCHK(dalloc(e, &e->t_z2, 2 * BH));
   RCCHK(dalloc(e, &e->q, 2 * B)); RCCHK(dalloc(e, &e->qt, 2 * B)); RCCHK(dalloc(e, &e->y, B)); RCCHK(dalloc(e, &e->q_pi, 2 * B));
   RCCHK(dalloc(e, &e->dA, 2 * B * e->a4));
+  if (e->B >= BIG_BATCH) RCCHK(dalloc(e, &e->s_h1, 4 * BH));
   RCCHK(dalloc(e, &e->part, 2 * (size_t)e->nblk4 * NSLOT * HID)); RCCHK(dalloc(e, &e->part_s, 2 * (size_t)e->nblk4 * 2)); RCCHK(dalloc(e, &e->part_sa, (size_t)e->nblk4 * 2));
   RCCHK(dalloc(e, &e->p_x, (size_t)e->maxn * e->ldo)); RCCHK(dalloc(e, &e->p_z1, (size_t)e->maxn * HID));
   RCCHK(dalloc(e, &e->p_z2, (size_t)e->maxn * HID)); RCCHK(dalloc(e, &e->p_act, (size_t)e->maxn * e->a4));

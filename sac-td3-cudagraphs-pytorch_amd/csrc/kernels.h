@@ -8,6 +8,7 @@
 //   k_nt / k_nt_wide  Y = pro(A) W^T + b on v_mfma_f32_16x16x4_f32; pro = LayerNorm+ReLU of the producing layer applied to
 //                     the A fragments in registers; optionally the FIRST layer (x W1^T + b1) is computed in the same kernel
 //                     straight into those fragments (narrow inputs); W tiles parked in LDS, block shape picked per launch
+//   k_nt64 / k_ln_fwd large-batch form of the hidden layers: 64 x 64 LDS-tiled GEMM -> LayerNorm row kernel -> tiled GEMM
 //   k_nn              dX = dY W                     (16 x 16 tile per block, reduction split over the 4 waves)
 //   k_tn              dW = dY^T X for every weight of an update in one launch (+ bias gradient, LayerNorm-affine / head
 //                     gradients from row partials) with the Adam step, Polyak update and loss finalisation in the epilogue
@@ -554,6 +555,106 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
       if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bias;
     }
   }
+}
+
+// ---- large-batch form (M >= 1024): the layers are big enough to be MFMA-bound, so they run as a classic LDS-tiled GEMM
+// (64 x 64 outputs per block, K streamed in 32-wide chunks through a double-buffered LDS stage, every operand byte
+// fetched once per block with full-line loads) with the LayerNorm+ReLU between them as a row kernel of its own.
+#define KC64 32
+#define LS64 (KC64 + 4)
+__global__ __launch_bounds__(256) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
+  __shared__ __attribute__((aligned(16))) float As[2][64 * LS64];
+  __shared__ __attribute__((aligned(16))) float Ws[2][64 * LS64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
+  const int r = lane & 15, kq = lane >> 4;
+  if (blockIdx.x == 0 && t == 0 && net == 0) {
+    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
+    if (p.tick1) *p.tick1 += 1;
+  }
+  const int grp = net / p.npg, ni = net - grp * p.npg;
+  const NtGrp G = p.g[grp];
+  const float* Pn = G.P + ni * p.p_ns;
+  const float* A = G.in + ni * p.in_ns;
+  const int tiles_n = (p.N + 63) >> 6;
+  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  const int m0 = bm * 64, n0 = bn * 64;
+  // staging map: thread -> (row = i >> 3, 16-byte column c4 = i & 7) for i = t and t + 256: 64 rows x 32 floats per operand
+  const int sr0 = t >> 3, sc = (t & 7) * 4;
+  const int am0 = min(m0 + sr0, p.M - 1), am1 = min(m0 + sr0 + 32, p.M - 1);
+  const int wn0 = min(n0 + sr0, p.N - 1), wn1 = min(n0 + sr0 + 32, p.N - 1);
+  const float* a0p = A + (long)am0 * p.ld_in; const float* a1p = A + (long)am1 * p.ld_in;
+  const float* w0p = Pn + p.oW + (long)wn0 * p.ldw; const float* w1p = Pn + p.oW + (long)wn1 * p.ldw;
+  const int Kr = (p.K + 3) & ~3;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int nc = (p.K + KC64 - 1) / KC64;
+  float4 ra0, ra1, rw0, rw1;
+  auto fetch = [&](int c) {
+    const int k = c * KC64 + sc;
+    const bool on = k < Kr;
+    ra0 = on ? zero_beyond(ld4(a0p + k), k, p.K) : f4(0.f); ra1 = on ? zero_beyond(ld4(a1p + k), k, p.K) : f4(0.f);
+    rw0 = on ? zero_beyond(ld4(w0p + k), k, p.K) : f4(0.f); rw1 = on ? zero_beyond(ld4(w1p + k), k, p.K) : f4(0.f);
+  };
+  auto park = [&](int buf) {
+    st4(As[buf] + sr0 * LS64 + sc, ra0); st4(As[buf] + (sr0 + 32) * LS64 + sc, ra1);
+    st4(Ws[buf] + sr0 * LS64 + sc, rw0); st4(Ws[buf] + (sr0 + 32) * LS64 + sc, rw1);
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nc) fetch(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
+    const float* ab = As[buf] + (16 * wave + r) * LS64 + 4 * kq;
+    const float* wb = Ws[buf] + r * LS64 + 4 * kq;
+#pragma unroll
+    for (int s2 = 0; s2 < KC64 / 16; ++s2) {
+      const float4 a = ld4(ab + 16 * s2);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const float4 b = ld4(wb + (16 * tt) * LS64 + 16 * s2);
+        MFMA4(acc[tt], a, b);
+      }
+    }
+    if (c + 1 < nc) park(buf ^ 1);
+    __syncthreads();
+  }
+  float* y = G.Y + ni * p.y_ns;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int col = n0 + 16 * tt + (lane & 15);
+    if (col >= p.N) continue;
+    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 16 * wave + 4 * (lane >> 4) + i;
+      if (row < p.M) y[(long)row * p.ldy + col] = acc[tt][i] + bias;
+    }
+  }
+}
+
+struct LnFwd {               // h = relu(LN(z) * gamma + beta) per row; stores h, xhat, rstd   (nets on blockIdx.y)
+  const float* P[2]; int npg; int oG, oBe; long p_ns;
+  float* h[2]; float* xh[2]; float* rstd[2];     // per group; xh / rstd may be null
+  const float* zin[2];                           // per group input rows [npg][B][HID]
+  int B, ln;
+};
+__global__ __launch_bounds__(256) void k_ln_fwd(LnFwd p) {
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15, net = blockIdx.y;
+  const int grp = net / p.npg, ni = net - grp * p.npg;
+  const int b = blockIdx.x * 16 + row;
+  if (b >= p.B) return;
+  const long ro = ((long)ni * p.B + b) * HID;
+  const float* Pn = p.P[grp] + ni * p.p_ns;
+  const Row16 z = row_ld(p.zin[grp] + ro, sub);
+  Row16 g, be, xh, y, hh;
+  if (p.ln) { g = row_ld(Pn + p.oG, sub); be = row_ld(Pn + p.oBe, sub); }
+  float rstd;
+  ln_fwd(z, g, be, p.ln, xh, y, rstd);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hh.v[q] = relu4(y.v[q]);
+  row_st(p.h[grp] + ro, sub, hh);
+  if (p.xh[grp]) row_st(p.xh[grp] + ro, sub, xh);
+  if (p.rstd[grp] && sub == 0) p.rstd[grp][(long)ni * p.B + b] = rstd;
 }
 
 struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Kout] ; block = one 16 x 16 tile, n split over waves
