@@ -68,14 +68,38 @@ struct NetLayout {   // float offsets inside one net's parameter block (all mult
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned magic) { return magic ? __umulhi(n, magic) : n / d; }
 // one thread: advance an optimiser's step count and publish the step's Adam scalars (torch.optim.Adam bias corrections)
 __device__ __forceinline__ void adam_tick(int* t, double* pw, float* out, float lr, float b1, float b2) {
-  *t += 1;
+  const int tv = *t;
+  double q0 = 0.0, q1 = 0.0;
+  if (out) { q0 = pw[0]; q1 = pw[1]; }
+  *t = tv + 1;
   if (out) {
-    const double p1 = pw[0] * (double)b1, p2 = pw[1] * (double)b2;
+    const double p1 = q0 * (double)b1, p2 = q1 * (double)b2;
     pw[0] = p1; pw[1] = p2;
     out[0] = (float)((double)lr / (1.0 - p1));
     out[1] = (float)sqrt(1.0 - p2);
   }
 }
+// The counter work of a launch (done by one thread of block 0): step counter + this step's Adam scalars, and a second
+// counter.  Absent targets are pointed at a sink so that all loads go out together, before any of the stores -- three
+// dependent load -> store round trips in front of block 0's work are a microsecond of critical path.
+__device__ int g_sink_i[2];
+__device__ double g_sink_d[2];
+__device__ float g_sink_f[2];
+__device__ __forceinline__ void tick_all(int* t0, int* t1, double* pw, float* out, float lr, float b1, float b2) {
+  const bool pub = t0 != nullptr && out != nullptr;
+  t0 = t0 ? t0 : g_sink_i; t1 = t1 ? t1 : g_sink_i + 1;
+  pw = pub ? pw : g_sink_d; out = pub ? out : g_sink_f;
+  const int a = *t0, b = *t1;
+  const double q0 = pw[0], q1 = pw[1];
+  const double p1 = q0 * (double)b1, p2 = q1 * (double)b2;
+  *t0 = a + 1; *t1 = b + 1;
+  pw[0] = p1; pw[1] = p2;
+  out[0] = (float)((double)lr / (1.0 - p1));
+  out[1] = (float)sqrt(1.0 - p2);
+}
+// Make a loaded value materialise HERE: without it the compiler sinks an early load into the (divergent) epilogue
+// branch that uses it, and every conditional store there then drains the memory queue (s_waitcnt vmcnt(0)) in turn.
+#define PIN(x) asm volatile("" : "+v"(x))
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
@@ -107,14 +131,17 @@ __device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x
 __device__ __forceinline__ float4 gate4(float4 v, float4 y) {  // v where y > 0 else 0
   return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
 }
-__device__ __forceinline__ float4 zero_beyond(float4 v, int k, int K) {  // element i of v is column k + i; zero columns >= K
-  if (k + 3 >= K) {
-    if (k >= K) v.x = 0.f;
-    if (k + 1 >= K) v.y = 0.f;
-    if (k + 2 >= K) v.z = 0.f;
-    v.w = 0.f;
-  }
-  return v;
+// Columns k .. k+3 of a row that holds Kr = round4(K) floats, zero beyond column K (and everywhere when !row_ok).  The load
+// is always issued (address clamped into the row) and masked with selects: a branch on `k < K` around the load makes
+// the compiler wait for each load before it issues the next one, which serialises a whole operand fetch.
+__device__ __forceinline__ float4 ld4_cols(const float* row, int k, int K, int Kr, bool row_ok = true) {
+  const float4 v = ld4(row + min(k, Kr - 4));
+  float4 o;
+  o.x = (row_ok && k < K) ? v.x : 0.f;
+  o.y = (row_ok && k + 1 < K) ? v.y : 0.f;
+  o.z = (row_ok && k + 2 < K) ? v.z : 0.f;
+  o.w = (row_ok && k + 3 < K) ? v.w : 0.f;
+  return o;
 }
 
 // standard normal for element e of (ctr, site): 4 normals per Philox block via two Box-Muller pairs
@@ -135,6 +162,10 @@ __device__ __forceinline__ Row16 row_ld(const float* row, int sub) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) r.v[q] = ld4(row + 4 * sub + 64 * q);
   return r;
+}
+__device__ __forceinline__ void row_pin(Row16& r) {      // see PIN
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { PIN(r.v[q].x); PIN(r.v[q].y); PIN(r.v[q].z); PIN(r.v[q].w); }
 }
 __device__ __forceinline__ void row_st(float* row, int sub, const Row16& r) {
 #pragma unroll
@@ -205,24 +236,30 @@ __device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block,
   const int ctr = p.ctl->sample_ctr, len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
   const unsigned g0 = block * 256u + threadIdx.x;
   const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = nblocks * 256u;   // host guarantees B * rec4 < 2^31
-  int bb[GATHER_CPT], cc[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT];
+  int bb[GATHER_CPT], cc[GATHER_CPT], ids[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT], first[GATHER_CPT];
+  // All loads first, all stores afterwards: a store that may alias a later load makes the compiler drain the memory
+  // queue (s_waitcnt vmcnt(0)) in between, which would serialise the record fetches.
 #pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) {            // consecutive threads -> consecutive chunks of a record
     const unsigned g = g0 + u * stride;
     on[u] = g < total;
     const unsigned q = on[u] ? fast_div(g, (unsigned)p.rec4, p.rec4_magic) : 0u;
     bb[u] = (int)q; cc[u] = on[u] ? (int)(g - q * (unsigned)p.rec4) : 0;
-    int id;
-    if (inject) id = p.idx[bb[u]];
-    else {
-      id = on[u] ? (int)philox_index(seed, (unsigned)ctr, (unsigned)bb[u], (unsigned)len) : 0;
-      if (on[u] && cc[u] == 0) p.idx[bb[u]] = id;
-    }
+    first[u] = !inject && on[u] && cc[u] == 0;
     on[u] = on[u] && cc[u] <= p.cx + p.cn;           // trailing pad chunk(s) are not moved
-    v[u] = on[u] ? p.ring[(long)id * p.rec4 + cc[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (inject) {
+#pragma unroll
+    for (int u = 0; u < GATHER_CPT; ++u) ids[u] = p.idx[bb[u]];
+  } else {
+#pragma unroll
+    for (int u = 0; u < GATHER_CPT; ++u) ids[u] = (int)philox_index(seed, (unsigned)ctr, (unsigned)bb[u], (unsigned)len);
   }
 #pragma unroll
+  for (int u = 0; u < GATHER_CPT; ++u) v[u] = p.ring[(long)ids[u] * p.rec4 + (on[u] ? cc[u] : 0)];
+#pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) {
+    if (first[u]) p.idx[bb[u]] = ids[u];
     if (!on[u]) continue;
     const int b = bb[u], c = cc[u];
     if (c < p.cx) p.X[(long)b * p.cx + c] = v[u];
@@ -339,8 +376,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int r = lane & 15, kq = lane >> 4;
   const int mt = wave / KS, ks = wave % KS;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
-    if (p.tick1) *p.tick1 += 1;
+    if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
@@ -351,6 +387,8 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int mrow = min(m0 + r, p.M - 1);
   const int kb = (ks * CW) * 16 + 4 * kq;                    // first k of this lane's fragments
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // requested here, used by the epilogue: a load issued among the epilogue's stores makes each store wait for the last
+  const float bias = p.oBias >= 0 ? Pn[p.oBias + min(n0 + r, p.N - 1)] : 0.f;
   STAMP(0);
   // ---- 1. every global load, coalesced where the data is shared by the block
   float4 w2r[4], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
@@ -370,7 +408,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
 #pragma unroll
     for (int c1 = 0; c1 < C1; ++c1) {
       const int k = 16 * c1 + 4 * kq;
-      xv[c1] = k < p.K1 ? zero_beyond(ld4(xrow + k), k, p.K1) : f4(0.f);
+      xv[c1] = ld4_cols(xrow, k, p.K1, (p.K1 + 3) & ~3);
     }
   } else {
 #pragma unroll
@@ -501,7 +539,6 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   STAMP(4);
   const int col = n0 + (lane & 15);
   if (ks == 0 && col < p.N) {
-    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
     float* y = G.Y + ni * p.y_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -518,8 +555,7 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
-    if (p.tick1) *p.tick1 += 1;
+    if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
@@ -529,25 +565,25 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
   const int m0 = tm * 16, n0 = tn * 16;
   const float* Arow = G.in + ni * p.in_ns + (long)min(m0 + r, p.M - 1) * p.ld_in;
   const float* Wrow = Pn + p.oW + (long)min(n0 + r, p.N - 1) * p.ldw;
-  const int chunks = (p.K + 15) >> 4;
+  const int chunks = (p.K + 15) >> 4, Kr = (p.K + 3) & ~3;
+  float bias = p.oBias >= 0 ? Pn[p.oBias + min(n0 + r, p.N - 1)] : 0.f;   // for the epilogue, requested up front
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < chunks; cb += 32) {
     float4 a[8], w[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = cb + wave + 4 * u, k = 16 * c + 4 * kq;
-      const bool on = c < chunks && k < p.K;
-      a[u] = on ? zero_beyond(ld4(Arow + k), k, p.K) : f4(0.f);
-      w[u] = on ? zero_beyond(ld4(Wrow + k), k, p.K) : f4(0.f);
+      a[u] = ld4_cols(Arow, k, p.K, Kr);
+      w[u] = ld4_cols(Wrow, k, p.K, Kr);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) { MFMA4(acc, a[u], w[u]); }
   }
+  PIN(bias);
   acc = splitk_reduce(red, acc, wave, lane);
   const int col = n0 + (lane & 15);
   if (wave == 0 && col < p.N) {
-    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
     float* y = G.Y + ni * p.y_ns;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -558,78 +594,95 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
 }
 
 // ---- large-batch form (M >= 1024): the layers are big enough to be MFMA-bound, so they run as a classic LDS-tiled GEMM
-// (64 x 64 outputs per block, K streamed in 32-wide chunks through a double-buffered LDS stage, every operand byte
+// (64 x 64 outputs per block, K streamed in 64-wide chunks through a double-buffered LDS stage, every operand byte
 // fetched once per block with full-line loads) with the LayerNorm+ReLU between them as a row kernel of its own.
-#define KC64 32
+// 8 waves per block, two per SIMD (wave = 16 rows x 32 columns): a SIMD issues its waves in order, so with a single
+// wave the LDS fragment reads, the parking of the next chunk and the barrier all sit in front of the MFMAs; a second
+// wave fills those gaps (measured at B = 1024, K = 256: 4000 -> see DESIGN.md cycles per 64-wide chunk, MFMA alone is 2048).
+#define KC64 64
 #define LS64 (KC64 + 4)
-__global__ __launch_bounds__(256) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
+__global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
   __shared__ __attribute__((aligned(16))) float As[2][64 * LS64];
   __shared__ __attribute__((aligned(16))) float Ws[2][64 * LS64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave & 3, wn = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
-  if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0) adam_tick(p.tick0, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
-    if (p.tick1) *p.tick1 += 1;
+  if (blockIdx.x == 0 && t == 0) {
+    if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
+  // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a contiguous run of tiles (half a net's 16 x 4 tile
+  // grid at B = 1024) so that the A-row and W-column tiles its 32 CUs share are fetched into that XCD's L2 once.
+  const int tiles_n = (p.N + 63) >> 6, tiles = tiles_n * ((p.M + 63) >> 6);
+  int L = blockIdx.x;
+  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }
+  const int net = L / tiles, idx = L - net * tiles;
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
   const float* Pn = G.P + ni * p.p_ns;
   const float* A = G.in + ni * p.in_ns;
-  const int tiles_n = (p.N + 63) >> 6;
-  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  const int bm = idx / tiles_n, bn = idx - bm * tiles_n;
   const int m0 = bm * 64, n0 = bn * 64;
-  // staging map: thread -> (row = i >> 3, 16-byte column c4 = i & 7) for i = t and t + 256: 64 rows x 32 floats per operand
-  const int sr0 = t >> 3, sc = (t & 7) * 4;
-  const int am0 = min(m0 + sr0, p.M - 1), am1 = min(m0 + sr0 + 32, p.M - 1);
-  const int wn0 = min(n0 + sr0, p.N - 1), wn1 = min(n0 + sr0 + 32, p.N - 1);
-  const float* a0p = A + (long)am0 * p.ld_in; const float* a1p = A + (long)am1 * p.ld_in;
-  const float* w0p = Pn + p.oW + (long)wn0 * p.ldw; const float* w1p = Pn + p.oW + (long)wn1 * p.ldw;
+  // staging map: thread -> rows (t >> 4) + 32 u, u = 0..1, 16-byte column (t & 15): 64 rows x 64 floats per operand
+  const int sr0 = t >> 4, sc = (t & 15) * 4;
+  const float* ap[2]; const float* wp[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    ap[u] = A + (long)min(m0 + sr0 + 32 * u, p.M - 1) * p.ld_in;
+    wp[u] = Pn + p.oW + (long)min(n0 + sr0 + 32 * u, p.N - 1) * p.ldw;
+  }
   const int Kr = (p.K + 3) & ~3;
-  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const int nc = (p.K + KC64 - 1) / KC64;
-  float4 ra0, ra1, rw0, rw1;
+  float bias[2];                                  // loaded up front: a load issued among the epilogue's stores would make
+#pragma unroll                                    // every store wait for the one before it
+  for (int tt = 0; tt < 2; ++tt) bias[tt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 32 * wn + 16 * tt + r, p.N - 1)] : 0.f;
+  float4 ra[2], rw[2];
   auto fetch = [&](int c) {
     const int k = c * KC64 + sc;
-    const bool on = k < Kr;
-    ra0 = on ? zero_beyond(ld4(a0p + k), k, p.K) : f4(0.f); ra1 = on ? zero_beyond(ld4(a1p + k), k, p.K) : f4(0.f);
-    rw0 = on ? zero_beyond(ld4(w0p + k), k, p.K) : f4(0.f); rw1 = on ? zero_beyond(ld4(w1p + k), k, p.K) : f4(0.f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { ra[u] = ld4_cols(ap[u], k, p.K, Kr); rw[u] = ld4_cols(wp[u], k, p.K, Kr); }
   };
   auto park = [&](int buf) {
-    st4(As[buf] + sr0 * LS64 + sc, ra0); st4(As[buf] + (sr0 + 32) * LS64 + sc, ra1);
-    st4(Ws[buf] + sr0 * LS64 + sc, rw0); st4(Ws[buf] + (sr0 + 32) * LS64 + sc, rw1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st4(As[buf] + (sr0 + 32 * u) * LS64 + sc, ra[u]);
+      st4(Ws[buf] + (sr0 + 32 * u) * LS64 + sc, rw[u]);
+    }
   };
+  STAMP(0);
   fetch(0);
   park(0);
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int buf = c & 1;
     if (c + 1 < nc) fetch(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
-    const float* ab = As[buf] + (16 * wave + r) * LS64 + 4 * kq;
-    const float* wb = Ws[buf] + r * LS64 + 4 * kq;
+    const float* ab = As[buf] + (16 * wm + r) * LS64 + 4 * kq;
+    const float* wb = Ws[buf] + (32 * wn + r) * LS64 + 4 * kq;
 #pragma unroll
     for (int s2 = 0; s2 < KC64 / 16; ++s2) {
-      const float4 a = ld4(ab + 16 * s2);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const float4 b = ld4(wb + (16 * tt) * LS64 + 16 * s2);
-        MFMA4(acc[tt], a, b);
-      }
+      const float4 a = ld4(ab + 16 * s2), b0 = ld4(wb + 16 * s2), b1 = ld4(wb + 16 * LS64 + 16 * s2);
+      // the two column tiles' accumulators are independent: interleaved, no MFMA waits on its predecessor
+#define MFMA_ROW(c)                                                                     \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c, b0.c, acc[0], 0, 0, 0);         \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c, b1.c, acc[1], 0, 0, 0);
+      MFMA_ROW(x) MFMA_ROW(y) MFMA_ROW(z) MFMA_ROW(w)
+#undef MFMA_ROW
     }
     if (c + 1 < nc) park(buf ^ 1);
     __syncthreads();
   }
+  STAMP(1);
   float* y = G.Y + ni * p.y_ns;
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int col = n0 + 16 * tt + (lane & 15);
+  for (int tt = 0; tt < 2; ++tt) {
+    const int col = n0 + 32 * wn + 16 * tt + r;
     if (col >= p.N) continue;
-    const float bias = p.oBias >= 0 ? Pn[p.oBias + col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + 16 * wave + 4 * (lane >> 4) + i;
-      if (row < p.M) y[(long)row * p.ldy + col] = acc[tt][i] + bias;
+      const int row = m0 + 16 * wm + 4 * kq + i;
+      if (row < p.M) y[(long)row * p.ldy + col] = acc[tt][i] + bias[tt];
     }
   }
+  STAMP(2);
 }
 
 struct LnFwd {               // h = relu(LN(z) * gamma + beta) per row; stores h, xhat, rstd   (nets on blockIdx.y)
@@ -646,8 +699,9 @@ __global__ __launch_bounds__(256) void k_ln_fwd(LnFwd p) {
   const long ro = ((long)ni * p.B + b) * HID;
   const float* Pn = p.P[grp] + ni * p.p_ns;
   const Row16 z = row_ld(p.zin[grp] + ro, sub);
-  Row16 g, be, xh, y, hh;
-  if (p.ln) { g = row_ld(Pn + p.oG, sub); be = row_ld(Pn + p.oBe, sub); }
+  Row16 g = row_ld(Pn + (p.ln ? p.oG : 0), sub), be = row_ld(Pn + (p.ln ? p.oBe : 0), sub);   // unconditional: one batch of requests
+  row_pin(g); row_pin(be);
+  Row16 xh, y, hh;
   float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
 #pragma unroll
@@ -789,6 +843,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       if (lane == 0) sst = adam_fetch(p, nbase + q.fin_s_off);
     }
   }
+  // block 0's extras (loss finalisation, counter tick): operands requested here as well
+  const bool extras = blockIdx.x == 0 && net == 0 && wave == 2;
+  float loss_acc = 0.f; int tick_v = 0;
+  if (extras) {
+    if (p.loss_dst) for (int i = lane; i < p.loss_n; i += 64) loss_acc += p.loss_part[(long)i * p.loss_stride + p.loss_off];
+    if (lane == 0 && p.tick) tick_v = *p.tick;
+  }
   // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
   const float* dYn = q.dY + net * q.dy_ns;
   const float* Xn = q.X + net * q.x_ns;
@@ -801,8 +862,9 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
-      vy[u] = (m < p.M && n < Nr) ? zero_beyond(ld4(dYn + (long)m * q.ldy + n), n, q.N) : f4(0.f);
-      vx[u] = (m < p.M && k < Kr) ? zero_beyond(ld4(Xn + (long)m * q.ldx + k), k, q.K) : f4(0.f);
+      const long mc = min(m, p.M - 1);
+      vy[u] = ld4_cols(dYn + mc * q.ldy, n, q.N, Nr, m < p.M);
+      vx[u] = ld4_cols(Xn + mc * q.ldx, k, q.K, Kr, m < p.M);
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
@@ -867,14 +929,12 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
   }
   STAMP(4);
-  if (blockIdx.x == 0 && net == 0 && wave == 2) {
+  if (extras) {
     if (p.loss_dst) {
-      float s = 0.f;
-      for (int i = lane; i < p.loss_n; i += 64) s += p.loss_part[(long)i * p.loss_stride + p.loss_off];
-      s = wave_sum(s);
+      const float s = wave_sum(loss_acc);
       if (lane == 0) *p.loss_dst = s * p.loss_scale;
     }
-    if (lane == 0 && p.tick) *p.tick += 1;
+    if (lane == 0 && p.tick) *p.tick = tick_v + 1;
   }
 }
 
@@ -901,6 +961,7 @@ struct ActorTail {
 };
 
 // the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
+// (only for output elements beyond a thread's first, i.e. ac_dim > 16: the first one is handled branch-free in the kernel)
 __device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr_add,
                                            int bc, int b, int j, bool valid) {
   if (p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
@@ -912,6 +973,10 @@ __device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, i
   return need_eps ? tail_draw(p, p.site_buf, p.site_code, p.eps, p.ctr_add, bc, b, j, valid) : 0.f;
 }
 
+// Memory discipline of this kernel (and of every kernel here): ALL global loads of the common case go out first, behind
+// uniform branches only and with clamped addresses + selects instead of per-lane conditions; they are made to land
+// (PIN) before the first global store.  A load that follows a store, or one that is first used inside a divergent
+// branch, costs a full drain of the memory queue (s_waitcnt vmcnt(0)) -- a round trip each, and there were ~20 here.
 __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   __shared__ __attribute__((aligned(16))) float Hs[16 * AS];
   __shared__ float Up[4 * 16 * 64];
@@ -921,27 +986,45 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   const bool valid = b < p.B;
   const int nh = p.L.nh, T = (nh + 15) >> 4;     // head column tiles (<= 4)
   const float* Wh = p.P + p.L.Wh;
-  if (p.tick && blockIdx.x == 0 && t == 0) *p.tick += 1;
   STAMP(0);
-  // loads first: my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3)
+  // ---- loads: counter, stream state, my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3),
+  // the operands of this thread's first output element (j = sub), its injected draws, the observation slice to copy
+  const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
+  int tick_v = 0;
+  if (ticker) tick_v = *p.tick;
+  const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
+  const int inj1 = need_eps ? p.ctl->inject_eps[p.site_buf] : 0, inj2 = p.dual ? p.ctl->inject_eps[p.site_buf2] : 0;
+  const unsigned long long seed = p.ctl->seed;
+  const int ctr = *p.ctr;
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
-  Row16 g, be;
-  if (p.ln) { g = row_ld(p.P + p.L.g2, sub); be = row_ld(p.P + p.L.be2, sub); }
+  const Row16 g = row_ld(p.P + (p.ln ? p.L.g2 : 0), sub), be = row_ld(p.P + (p.ln ? p.L.be2 : 0), sub);
   float4 wf[4][4];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
-      const int n = tt * 16 + r;
-      wf[tt][ci] = (tt < T && n < nh) ? ld4(Wh + (long)n * HID + (4 * wave + ci) * 16 + 4 * kq) : f4(0.f);
+      // unconditional, row clamped (tiles beyond the head re-read its last row: L1 hits); rows >= nh are zeroed
+      // after the loads are in -- not here, where a select on the value would wait for it
+      wf[tt][ci] = ld4(Wh + (long)min(tt * 16 + r, nh - 1) * HID + (4 * wave + ci) * 16 + 4 * kq);
     }
-  // operands of this thread's first output element (j = sub) and its noise draw: requested / computed up front
-  const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
   const int j0 = min(sub, p.a - 1);
-  const float e_bh0 = p.P[p.L.bh + j0], e_bh1 = p.sac ? p.P[p.L.bh + p.a + j0] : 0.f;
-  const float e_sc = p.scale[j0], e_bi = p.bias[j0];
-  const float e_eps = sub < p.a ? tail_noise(p, need_eps, bc, b, j0, valid) : 0.f;
-  const float e_eps2 = (p.dual && sub < p.a) ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j0, valid) : 0.f;
+  const long ej = (long)bc * p.a + j0;
+  float e_bh0 = p.P[p.L.bh + j0], e_bh1 = p.sac ? p.P[p.L.bh + p.a + j0] : 0.f;
+  float e_sc = p.scale[j0], e_bi = p.bias[j0];
+  const bool smooth = !p.sac && p.mode == 1;     // TD3 target smoothing clamps to the action bounds
+  float e_lo = 0.f, e_hi = 0.f;
+  if (smooth) { e_lo = p.min_ac[j0]; e_hi = p.max_ac[j0]; }
+  float e_in1 = 0.f, e_in2 = 0.f;
+  if (need_eps) e_in1 = p.eps[ej];               // fetched whether or not it is an injected draw: branching on the
+  if (p.dual) e_in2 = p.eps2[ej];                // (loaded) injection flag here would hold back every later request
+  float ob[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.obs_src) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ob[i] = p.obs_src[(long)bc * p.lds + min(sub + 16 * i, p.o - 1)];
+  }
+  // native draws (no memory involved)
+  const float e_nat1 = need_eps ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
+  const float e_nat2 = p.dual ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej) : 0.f;
   STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
@@ -949,14 +1032,37 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
   row_st(Hs + row * AS, sub, h);
+  // everything requested above has to be here before the first store goes out
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      PIN(wf[tt][ci].x); PIN(wf[tt][ci].y); PIN(wf[tt][ci].z); PIN(wf[tt][ci].w);
+      if (tt * 16 + r >= nh) wf[tt][ci] = f4(0.f);
+    }
+  PIN(e_bh0); PIN(e_bh1); PIN(e_sc); PIN(e_bi); PIN(e_lo); PIN(e_hi); PIN(e_in1); PIN(e_in2); PIN(tick_v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) PIN(ob[i]);
+  const float e_eps = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
+  const float e_eps2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
   if (valid) {
     if (p.train) {
       row_st(p.h2 + (long)b * HID, sub, h);
       row_st(p.xh2 + (long)b * HID, sub, xh);
       if (sub == 0) p.rstd2[b] = rstd;
     }
-    if (p.obs_src)
-      for (int k = sub; k < p.o; k += 16) p.dst[(long)b * p.ldd + k] = p.obs_src[(long)b * p.lds + k];
+    if (sub < p.a) {
+      if (need_eps && !inj1) p.eps[ej] = e_nat1;
+      if (p.dual && !inj2) p.eps2[ej] = e_nat2;
+    }
+    if (p.obs_src) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (sub + 16 * i < p.o) p.dst[(long)b * p.ldd + sub + 16 * i] = ob[i];
+      const float* __restrict__ src = p.obs_src + (long)b * p.lds;
+      float* __restrict__ dst = p.dst + (long)b * p.ldd;
+      for (int k = sub + 64; k < p.o; k += 16) dst[k] = src[k];
+    }
   }
   __syncthreads();
   STAMP(2);
@@ -979,16 +1085,13 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   __syncthreads();
   STAMP(3);
   float lp = 0.f, lp2 = 0.f;
-  for (int j = sub; j < p.a; j += 16) {
-    const bool first = j == sub;
+  auto element = [&](int j, float bh0, float bh1, float sc, float bi, float lo, float hi, float e, float e2) {
     const float* u = Up + row * 64;
-    const float u0 = ((u[j] + u[1024 + j]) + (u[2048 + j] + u[3072 + j])) + (first ? e_bh0 : p.P[p.L.bh + j]);
-    const float e = first ? e_eps : tail_noise(p, need_eps, bc, b, j, valid);
-    const float sc = first ? e_sc : p.scale[j], bi = first ? e_bi : p.bias[j];
+    const float u0 = ((u[j] + u[1024 + j]) + (u[2048 + j] + u[3072 + j])) + bh0;
     float act;
     if (p.sac) {
       const int j1 = p.a + j;
-      const float u1 = ((u[j1] + u[1024 + j1]) + (u[2048 + j1] + u[3072 + j1])) + (first ? e_bh1 : p.P[p.L.bh + j1]);
+      const float u1 = ((u[j1] + u[1024 + j1]) + (u[2048 + j1] + u[3072 + j1])) + bh1;
       const float tt = tanhf(u1);
       const float log_std = -5.0f + 3.5f * (tt + 1.0f);
       const float sd = expf(log_std);
@@ -1000,7 +1103,6 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       l -= logf(sc * (1.0f - yt * yt) + 1e-6f);
       lp += l;
       if (p.dual) {                                      // second draw: log-prob only
-        const float e2 = first ? e_eps2 : tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j, valid);
         const float x2 = u0 + e2 * sd, y2 = tanhf(x2), d2 = x2 - u0;
         lp2 += -(d2 * d2) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f - logf(sc * (1.0f - y2 * y2) + 1e-6f);
       }
@@ -1014,13 +1116,19 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       act = th * sc + bi;
       if (p.mode == 1) {
         const float nz = fminf(fmaxf(e * p.td3_std, -p.td3_c), p.td3_c);
-        act = fminf(fmaxf(act + nz, p.min_ac[j]), p.max_ac[j]);
+        act = fminf(fmaxf(act + nz, lo), hi);
       } else if (p.mode == 2) {
         act = act + e * (sc * p.noise_std);
       }
       if (p.train && valid) p.tg[(long)b * 4 * p.a4 + j] = th;
     }
     if (valid) p.dst[(long)b * p.ldd + p.dst_off + j] = act;
+  };
+  if (sub < p.a) element(sub, e_bh0, e_bh1, e_sc, e_bi, e_lo, e_hi, e_eps, e_eps2);       // operands already in registers
+  for (int j = sub + 16; j < p.a; j += 16) {                                   // ac_dim > 16 only
+    const float e = tail_noise(p, need_eps, bc, b, j, valid);
+    const float e2 = p.dual ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j, valid) : 0.f;
+    element(j, p.P[p.L.bh + j], p.sac ? p.P[p.L.bh + p.a + j] : 0.f, p.scale[j], p.bias[j], smooth ? p.min_ac[j] : 0.f, smooth ? p.max_ac[j] : 0.f, e, e2);
   }
   STAMP(4);
   if (p.sac && p.logp) {
@@ -1031,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     lp2 = row16_sum(lp2);
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
+  if (ticker) *p.tick = tick_v + 1;
   STAMP(5);
 }
 
@@ -1219,6 +1328,12 @@ __global__ __launch_bounds__(16 * RPB) void k_ln_bwd(LnBwd p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) { dy.v[q] = gate4(dh.v[q], hh.v[q]); if (!valid) dy.v[q] = f4(0.f); }
   const Row16 dz = ln_bwd(dy, xh, rstd, g, p.ln);
+  if (RPB == 16) {                       // the slice-product operands land before the first store goes out (see PIN)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) { PIN(wf[tt][ci].x); PIN(wf[tt][ci].y); PIN(wf[tt][ci].z); PIN(wf[tt][ci].w); }
+  }
   if (valid) row_st(p.dz + ((long)net * p.B + b) * HID, sub, dz);
   if (p.want_part) {
 #pragma unroll
@@ -1290,23 +1405,28 @@ __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
         if (k + 3 < nh) wf[tt][c].w = Wh[(long)(k + 3) * HID + n];
       }
     }
+  // operands of this thread's first head element (j = sub), requested with the rest (see k_actor_tail)
+  const int j0 = min(sub, p.a - 1);
+  const float* tgr = p.tg + (long)bc * 4 * p.a4;
+  float la = p.sac ? *p.log_alpha : 0.f;
+  float o_dA = p.dA[(long)bc * p.ldA + j0], o_dA1 = p.nq == 2 ? p.dA[p.dA_ns + (long)bc * p.ldA + j0] : 0.f;
+  float o_sc = p.scale[j0], o_t0 = tgr[j0];
+  float o_t1 = 0.f, o_t2 = 0.f, o_e = 0.f;
+  if (p.sac) { o_t1 = tgr[p.a4 + j0]; o_t2 = tgr[2 * p.a4 + j0]; o_e = p.eps[(long)bc * p.a + j0]; }
   for (int j = sub; j < 64; j += 16) Du[row * 68 + j] = 0.f;
+  PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
   __syncthreads();
-  const float dlogp = p.sac ? expf(*p.log_alpha) / (float)p.B : 0.f;
-  for (int j = sub; j < p.a; j += 16) {
-    float dAj = p.dA[(long)bc * p.ldA + j];
-    if (p.nq == 2) dAj += p.dA[p.dA_ns + (long)bc * p.ldA + j];
-    const float sc = p.scale[j];
-    const float* tg = p.tg + (long)bc * 4 * p.a4;
+  const float dlogp = p.sac ? expf(la) / (float)p.B : 0.f;
+  auto element = [&](int j, float dAj, float sc, float t0, float t1, float t2, float e) {
     float g_mean, g_raw = 0.f;
     if (p.sac) {
-      const float tt = tg[j], sd = tg[p.a4 + j], yt = tg[2 * p.a4 + j], e = p.eps[(long)bc * p.a + j];
+      const float tt = t0, sd = t1, yt = t2;
       const float omy2 = 1.0f - yt * yt;
       const float g0 = dAj * sc * omy2 + dlogp * (2.0f * sc * yt * omy2) / (sc * omy2 + 1e-6f);
       g_mean = g0;
       g_raw = (g0 * e * sd - dlogp) * 3.5f * (1.0f - tt * tt);
     } else {
-      const float th = tg[j];
+      const float th = t0;
       g_mean = dAj * sc * (1.0f - th * th);
     }
     if (!valid) { g_mean = 0.f; g_raw = 0.f; }
@@ -1316,6 +1436,12 @@ __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
       p.du[(long)b * p.ldu + j] = g_mean;
       if (p.sac) p.du[(long)b * p.ldu + p.a + j] = g_raw;
     }
+  };
+  if (sub < p.a) element(sub, o_dA + o_dA1, o_sc, o_t0, o_t1, o_t2, o_e);
+  for (int j = sub + 16; j < p.a; j += 16) {            // ac_dim > 16 only
+    float dAj = p.dA[(long)bc * p.ldA + j];
+    if (p.nq == 2) dAj += p.dA[p.dA_ns + (long)bc * p.ldA + j];
+    element(j, dAj, p.scale[j], tgr[j], p.sac ? tgr[p.a4 + j] : 0.f, p.sac ? tgr[2 * p.a4 + j] : 0.f, p.sac ? p.eps[(long)bc * p.a + j] : 0.f);
   }
   __syncthreads();
   // dh2[16][256] = du[16][nh] Wh[nh][256]; wave w owns column tiles w, w+4, w+8, w+12
@@ -1356,23 +1482,30 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   const float step = a.adam[0], sq2 = a.adam[1];   // published by the first kernel of the update (adam_tick)
   const float gs = a.gscale ? *a.gscale : 1.0f;
   const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
+  // block 0's extras: operands requested before the element loop, written after it (loads first, stores last)
+  const bool extras = blockIdx.x == 0 && threadIdx.x < 64;
+  float loss_acc = 0.f; int tick_v = 0;
+  if (extras) {
+    if (a.loss_dst) for (int i = threadIdx.x; i < a.loss_n; i += 64) loss_acc += a.loss_part[(long)i * a.loss_stride + a.loss_off];
+    if (threadIdx.x == 0 && a.tick) tick_v = *a.tick;
+  }
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (long)gridDim.x * 1024) {
     float4 g = ld4(a.g + i) * gs, m = ld4(a.m + i), v = ld4(a.v + i), p = ld4(a.p + i);
+    float4 tt = f4(0.f);
+    if (a.targ) tt = ld4(a.targ + i);
     m = m + (g - m) * omb1;
     v = v * a.b2 + g * g * omb2;
     p.x -= step * (m.x / (sqrtf(v.x) / sq2 + a.eps)); p.y -= step * (m.y / (sqrtf(v.y) / sq2 + a.eps));
     p.z -= step * (m.z / (sqrtf(v.z) / sq2 + a.eps)); p.w -= step * (m.w / (sqrtf(v.w) / sq2 + a.eps));
     st4(a.m + i, m); st4(a.v + i, v); st4(a.p + i, p);
-    if (a.targ) { const float4 tt = ld4(a.targ + i); st4(a.targ + i, tt + (p - tt) * a.tau); }
+    if (a.targ) st4(a.targ + i, tt + (p - tt) * a.tau);
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (extras) {
     if (a.loss_dst) {
-      float s = 0.f;
-      for (int i = threadIdx.x; i < a.loss_n; i += 64) s += a.loss_part[(long)i * a.loss_stride + a.loss_off];
-      s = wave_sum(s);
+      const float s = wave_sum(loss_acc);
       if (threadIdx.x == 0) *a.loss_dst = s * a.loss_scale;
     }
-    if (threadIdx.x == 0 && a.tick) *a.tick += 1;
+    if (threadIdx.x == 0 && a.tick) *a.tick = tick_v + 1;
   }
 }
 
@@ -1395,28 +1528,36 @@ struct AlphaArgs {
 };
 __global__ __launch_bounds__(256) void k_alpha_step(AlphaArgs a) {
   __shared__ float red[4];
+  // the lead thread's state is requested together with the log-probs: fetched one after the other behind the
+  // reduction it would be four dependent round trips in a kernel that does nothing else
+  const bool lead = threadIdx.x == 0;
+  float la = 0.f, m = 0.f, v = 0.f; int tl = 0, tk = 0; double q0 = 0.0, q1 = 0.0;
+  if (lead) {
+    la = a.la[0];
+    if (a.autotune) { m = a.la[1]; v = a.la[2]; tl = a.ctl->t_l; q0 = a.ctl->pw_l[0]; q1 = a.ctl->pw_l[1]; }
+    if (a.tick) tk = *a.tick;
+  }
   float s = 0.f;
   if (a.autotune)
     for (int i = threadIdx.x; i < a.B; i += 256) s += -a.logp[i] - a.targ_ent;
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float la = a.la[0];
+  if (lead) {
     if (a.autotune) {
       const float mean_term = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
       const float g = expf(la) * mean_term;          // d/dlog_alpha of alpha * mean_term; also the loss value
       a.ctl->metrics[2] = g;
-      float sc[2];
-      adam_tick(&a.ctl->t_l, a.ctl->pw_l, sc, a.lr, a.b1, a.b2);
-      float m = a.la[1], v = a.la[2];
+      const double p1 = q0 * (double)a.b1, p2 = q1 * (double)a.b2;      // adam_tick on (t_l, pw_l)
+      a.ctl->t_l = tl + 1; a.ctl->pw_l[0] = p1; a.ctl->pw_l[1] = p2;
+      const float sc0 = (float)((double)a.lr / (1.0 - p1)), sc1 = (float)sqrt(1.0 - p2);
       m = m + (g - m) * (1.0f - a.b1);
       v = v * a.b2 + g * g * (1.0f - a.b2);
-      la -= sc[0] * (m / (sqrtf(v) / sc[1] + a.eps));
+      la -= sc0 * (m / (sqrtf(v) / sc1 + a.eps));
       a.la[0] = la; a.la[1] = m; a.la[2] = v;
     }
     a.ctl->metrics[3] = expf(la);
-    if (a.tick) *a.tick += 1;
+    if (a.tick) *a.tick = tk + 1;
   }
 }
 
