@@ -231,9 +231,10 @@ struct GatherArgs {
 
 #define GATHER_CPT 4    // float4 chunks per thread: loads in flight per lane
 __device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block, unsigned nblocks) {
-  const int inject = p.ctl->inject_idx;
+  // one batch of requests for the sampling state (a field read behind a branch on another field is a second round trip)
+  const int inject = p.ctl->inject_idx, rb_len = p.ctl->rb_len, ctr = p.ctl->sample_ctr;
   const unsigned long long seed = p.ctl->seed;
-  const int ctr = p.ctl->sample_ctr, len = p.len_override >= 0 ? p.len_override : p.ctl->rb_len;
+  const int len = p.len_override >= 0 ? p.len_override : rb_len;
   const unsigned g0 = block * 256u + threadIdx.x;
   const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = nblocks * 256u;   // host guarantees B * rec4 < 2^31
   int bb[GATHER_CPT], cc[GATHER_CPT], ids[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT], first[GATHER_CPT];
@@ -396,13 +397,15 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   if (FUSE1) {
 #pragma unroll
     for (int u = 0; u < 4 * C1; ++u) {                        // ldw1 <= 16 C1 floats -> at most 4 C1 float4 per thread
-      const int f = t + 256 * u;
-      w1r[u] = f < w1n ? ld4(Pn + p.oW1 + 4 * (long)f) : f4(0.f);
+      const int f = min(t + 256 * u, w1n - 1);               // clamped, not predicated: parked only where t + 256 u < w1n
+      w1r[u] = ld4(Pn + p.oW1 + 4 * (long)f);
     }
     const float* xrow = G.in + ni * p.in_ns + (long)mrow * p.ld_in;
     if (p.ring_rows) {                                       // this sample's record in the replay ring
-      const int id = p.ga.ctl->inject_idx ? p.ga.idx[mrow]
-                                          : (int)philox_index(p.ga.ctl->seed, (unsigned)p.ga.ctl->sample_ctr, (unsigned)mrow, (unsigned)p.ga.ctl->rb_len);
+      const int inject = p.ga.ctl->inject_idx, rb_len = p.ga.ctl->rb_len, sctr = p.ga.ctl->sample_ctr;   // one batch of requests
+      const unsigned long long seed = p.ga.ctl->seed;
+      int id = (int)philox_index(seed, (unsigned)sctr, (unsigned)mrow, (unsigned)max(rb_len, 1));
+      if (inject) id = p.ga.idx[mrow];
       xrow = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + p.ring_off;
     }
 #pragma unroll
@@ -815,13 +818,32 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   // the epilogue's elements: wave 0, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + j
   const int ecol = k0 + (lane & 15);
   AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
-  const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
   STAMP(0);
+  // Requests go out in the order main operands -> optimiser state -> vector-gradient partials, so that the waits the
+  // partial-sum loops contain fall under the latency of the operand fetch instead of in front of it.
+  // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
+  const float* dYn = q.dY + net * q.dy_ns;
+  const float* Xn = q.X + net * q.x_ns;
+  const int Nr = (q.N + 3) & ~3, Kr = (q.K + 3) & ~3;     // rows hold at least round4(.) floats
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
+  float4 vy[4], vx[4];
+  auto fetch = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
+      const long mc = min(m, p.M - 1);
+      vy[u] = ld4_cols(dYn + mc * q.ldy, n, q.N, Nr, m < p.M);
+      vx[u] = ld4_cols(Xn + mc * q.ldx, k, q.K, Kr, m < p.M);
+    }
+  };
+  fetch(0);
+  const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
   if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = n0 + 4 * (lane >> 4) + i;
-      st[i] = (row < q.N && ecol < q.ldw) ? adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + ecol) : sv;
+    for (int i = 0; i < 4; ++i) {          // clamped, not predicated (the commit is predicated)
+      const int row = min(n0 + 4 * (lane >> 4) + i, q.N - 1);
+      st[i] = adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + min(ecol, q.ldw - 1));
     }
   }
   // k-tile-0 blocks also finalise the vector gradients of their 16 columns: request those operands and the
@@ -833,8 +855,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
 #pragma unroll
     for (int e = 0; e < 3; ++e)
       if (e < q.nfin && fn < q.N) {
-        for (int blk = fpart; blk < q.fin_nblk[e]; blk += 16)
-          fsum[e] += p.part[(((long)net * p.pstride + blk) * NSLOT + q.fin_slot[e]) * HID + fn];
+        const int nb = q.fin_nblk[e];
+        const float* pp = p.part + ((long)net * p.pstride * NSLOT + q.fin_slot[e]) * HID + fn;
+        for (int blk = fpart; blk < nb; blk += 64) {       // 4 independent requests per trip (one trip up to B = 1024)
+          const float v0 = pp[(long)blk * NSLOT * HID], v1 = pp[(long)min(blk + 16, nb - 1) * NSLOT * HID];
+          const float v2 = pp[(long)min(blk + 32, nb - 1) * NSLOT * HID], v3 = pp[(long)min(blk + 48, nb - 1) * NSLOT * HID];
+          fsum[e] += (v0 + (blk + 16 < nb ? v1 : 0.f)) + ((blk + 32 < nb ? v2 : 0.f) + (blk + 48 < nb ? v3 : 0.f));
+        }
         if (t < 16) fst[e] = adam_fetch(p, nbase + q.fin_off[e] + fn);
       }
     if (q.b_off >= 0 && t < 16 && fn < q.N) bst = adam_fetch(p, nbase + q.b_off + fn);
@@ -850,22 +877,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     if (p.loss_dst) for (int i = lane; i < p.loss_n; i += 64) loss_acc += p.loss_part[(long)i * p.loss_stride + p.loss_off];
     if (lane == 0 && p.tick) tick_v = *p.tick;
   }
-  // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
-  const float* dYn = q.dY + net * q.dy_ns;
-  const float* Xn = q.X + net * q.x_ns;
-  const int Nr = (q.N + 3) & ~3, Kr = (q.K + 3) & ~3;     // rows hold at least round4(.) floats
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
   for (int mb = 0; mb < p.M; mb += 256) {
     if (mb) __syncthreads();
-    float4 vy[4], vx[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
-      const long mc = min(m, p.M - 1);
-      vy[u] = ld4_cols(dYn + mc * q.ldy, n, q.N, Nr, m < p.M);
-      vx[u] = ld4_cols(Xn + mc * q.ldx, k, q.K, Kr, m < p.M);
-    }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
 #pragma unroll
@@ -874,6 +887,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]);
       st4(Xs + (i >> 2) * YS + 4 * (i & 3), vx[u]);
     }
+    if (mb + 256 < p.M) fetch(mb + 256);                   // the next slab's rows fly under this slab's MFMAs
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                          // wave w: 16-row chunks w, w+4, w+8, w+12 of this slab
