@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
   __shared__ __attribute__((aligned(16))) float Xs[256 * YS];
-  __shared__ float cred[16 * 17];
+  __shared__ float cred[4 * 16 * 17];                    // [entry: 3 finalised vectors + the bias][16 partial groups][16 columns]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   int pi = 0;
@@ -850,7 +850,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   // optimiser state of the finalised elements now, so that the epilogue waits for nothing
   const int fcol = t & 15, fpart = t >> 4, fn = n0 + fcol;         // (column, partial-group) of this thread
   float fsum[3] = {0.f, 0.f, 0.f}, ssum = 0.f;
-  AdamState fst[3] = {sv, sv, sv}, bst = sv, sst = sv;
+  AdamState fstate = sv, sst = sv;
+  long foff = -1;
   if (tk == 0) {
 #pragma unroll
     for (int e = 0; e < 3; ++e)
@@ -862,9 +863,16 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
           const float v2 = pp[(long)min(blk + 32, nb - 1) * NSLOT * HID], v3 = pp[(long)min(blk + 48, nb - 1) * NSLOT * HID];
           fsum[e] += (v0 + (blk + 16 < nb ? v1 : 0.f)) + ((blk + 32 < nb ? v2 : 0.f) + (blk + 48 < nb ? v3 : 0.f));
         }
-        if (t < 16) fst[e] = adam_fetch(p, nbase + q.fin_off[e] + fn);
       }
-    if (q.b_off >= 0 && t < 16 && fn < q.N) bst = adam_fetch(p, nbase + q.b_off + fn);
+    // wave 3, lane (entry = lane >> 4, column = lane & 15), commits one finalised element: entries 0..2 are the vector
+    // gradients, entry 3 the bias gradient (column sums of dY, collected from the LDS tile in the main loop);
+    // wave 0 has the weight tile, wave 1 the scalar entry, wave 2 block 0's extras
+    if (wave == 3) {
+      const int e = lane >> 4;
+      const bool has = e < 3 ? e < q.nfin : q.b_off >= 0;
+      const int eoff = e == 0 ? q.fin_off[0] : (e == 1 ? q.fin_off[1] : (e == 2 ? q.fin_off[2] : q.b_off));
+      if (has && fn < q.N) { foff = nbase + eoff + fn; fstate = adam_fetch(p, foff); }
+    }
     if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
       for (int blk = lane; blk < q.fin_s_nblk; blk += 64) ssum += p.part_s[((long)net * p.pstride + blk) * 2];
       if (lane == 0) sst = adam_fetch(p, nbase + q.fin_s_off);
@@ -914,28 +922,17 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
   }
   if (tk == 0) {
-    if (q.b_off >= 0) {
-      cred[fpart * 17 + fcol] = asum;
-      __syncthreads();
-      if (t < 16 && fn < q.N) {
-        float s = 0.f;
+    // one LDS pass for all four entries (a barrier pair per entry was most of this epilogue)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += cred[i * 17 + t];
-        adam_commit(p, nbase + q.b_off + fn, s, bst, step, sq2);
-      }
-    }
+    for (int e = 0; e < 3; ++e) cred[(e * 16 + fpart) * 17 + fcol] = fsum[e];
+    cred[(3 * 16 + fpart) * 17 + fcol] = asum;
+    __syncthreads();
+    if (wave == 3 && foff >= 0) {
+      const float* c = cred + (lane >> 4) * 16 * 17 + fcol;
+      float v = 0.f;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {            // 16 threads per column hold the partial sums requested at the top
-      if (e >= q.nfin) break;
-      __syncthreads();
-      cred[fpart * 17 + fcol] = fsum[e];
-      __syncthreads();
-      if (t < 16 && fn < q.N) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += cred[i * 17 + t];
-        adam_commit(p, nbase + q.fin_off[e] + fn, v, fst[e], step, sq2);
-      }
+      for (int i = 0; i < 16; ++i) v += c[i * 17];
+      adam_commit(p, foff, v, fstate, step, sq2);
     }
     if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
       const float s = wave_sum(ssum);

@@ -84,8 +84,8 @@ int main() {
     float *q3, *dz, *part, *ps; CK(hipMalloc(&q3, 8 * B * 4)); CK(hipMalloc(&dz, 2 * B * 256 * 4)); CK(hipMalloc(&part, 2 * 64 * NSLOT * 256 * 4)); CK(hipMalloc(&ps, 2 * 64 * 2 * 4));
     NetLayout Lc = L; Lc.nh = 1;
     CriticTail c{}; c.z2t = Z2; c.z2 = Y; c.PT = P; c.P = P; c.p_ns = 80000; c.L = Lc; c.rew = logp; c.done = logp; c.logp_next = logp; c.log_alpha = sc + 4;
-    c.B = B; c.ln = 1; c.sac = 1; c.bcq = 0; c.gamma = 0.99f; c.qt = q3; c.y = q3 + 2 * B; c.q = q3 + 4 * B; c.dz2 = dz; c.part = part; c.part_s = ps; c.pstride = 64;
-    us = graph_us(s, [&] { hipLaunchKernelGGL(k_critic_tail<4>, dim3(64, 2), dim3(64), 0, s, c); }, 20, 50);
+    c.B = B; c.ln = 1; c.sac = 1; c.bcq = 0; c.gamma = 0.99f; c.qt = q3; c.y = q3 + 2 * B; c.q = q3 + 4 * B; c.dz2 = dz; c.part = part; c.part_s = ps; c.pstride = 16;
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_critic_tail<16>, dim3(16, 2), dim3(256), 0, s, c); }, 20, 50);
     show("k_critic_tail", us, 4);
   }
   return 0;
