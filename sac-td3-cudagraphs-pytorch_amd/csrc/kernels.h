@@ -1330,8 +1330,8 @@ __global__ __launch_bounds__(16 * RPB) void k_ln_bwd(LnBwd p) {
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
       wf[tt][ci] = f4(0.f);
-      if (tt < T && 16 * tt + r < p.na) {
-        const float* w = p.W1 + net * p.p_ns + (long)(16 * (4 * wave + ci) + 4 * kq) * p.ldw1 + p.k_off + 16 * tt + r;
+      if (T > 0) {                         // uniform; column clamped, lanes beyond na are zeroed once the loads are in
+        const float* w = p.W1 + net * p.p_ns + (long)(16 * (4 * wave + ci) + 4 * kq) * p.ldw1 + p.k_off + min(16 * tt + r, p.na - 1);
         wf[tt][ci] = make_float4(w[0], w[p.ldw1], w[2 * (long)p.ldw1], w[3 * (long)p.ldw1]);
       }
     }
@@ -1343,7 +1343,10 @@ __global__ __launch_bounds__(16 * RPB) void k_ln_bwd(LnBwd p) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) { PIN(wf[tt][ci].x); PIN(wf[tt][ci].y); PIN(wf[tt][ci].z); PIN(wf[tt][ci].w); }
+      for (int ci = 0; ci < 4; ++ci) {
+        PIN(wf[tt][ci].x); PIN(wf[tt][ci].y); PIN(wf[tt][ci].z); PIN(wf[tt][ci].w);
+        if (16 * tt + r >= p.na) wf[tt][ci] = f4(0.f);
+      }
   }
   if (valid) row_st(p.dz + ((long)net * p.B + b) * HID, sub, dz);
   if (p.want_part) {

@@ -76,3 +76,35 @@ def test_no_kernel_spills_to_scratch():
     assert len(names) == len(scratch) and len(names) >= 15, out[-2000:]
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, bad
+
+
+def test_no_serialised_operand_loads():
+    """A load first used inside a divergent branch, or issued after a possibly aliasing store, makes the compiler drain
+    the memory queue (s_waitcnt vmcnt(0)) before the next request goes out: an operand fetch written as
+    `k < K ? load : 0` waits a full round trip per load.  Check the compiled gfx950 code of every kernel: no run of
+    load -> drain -> load -> drain, and the GEMM kernels issue their operand fetch as one batch."""
+    import subprocess
+    csrc = os.path.join(ROOT, "sac-td3-cudagraphs-pytorch_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True)
+    txt = open("/tmp/sactd3_engine.s").read()
+    seqs = {}
+    for name in re.findall(r"^(_Z[\w]+):\s*;?.*$", txt, re.M):
+        i = txt.index("\n" + name + ":")
+        ev = []
+        for line in txt[i:txt.index(".Lfunc_end", i)].splitlines():
+            ins = line.strip()
+            if ins.startswith(("global_load", "buffer_load")):
+                ev.append("L")
+            elif ins.startswith(("global_store", "buffer_store")):
+                ev.append("S")
+            elif ins.startswith("s_waitcnt") and "vmcnt(0)" in ins:
+                ev.append("W")
+        seqs[name] = "".join(ev)
+    assert len(seqs) >= 15
+    for name, seq in seqs.items():
+        if "k_rb_fill" in name:          # synthetic-data filler of the bench, not on any path
+            continue
+        assert "LWLWLW" not in seq, (name, seq)
+    for key, batch in (("k_nt64", 4), ("k_nt_wide", 16), ("k_tn", 16), ("k_nn", 16), ("k_critic_tail", 32), ("k_actor_tail", 32)):
+        hit = [s for n, s in seqs.items() if key in n]
+        assert hit and all("L" * batch in s for s in hit), (key, hit)
