@@ -85,6 +85,54 @@ def oracle_rate(w, device, seconds, threads=None, min_iters=0):
     return i / (time.perf_counter() - t0), i
 
 
+def parity_deltas(w, device_id, iters=6):
+    """SURVEY 8(d) 'parity deltas': `iters` iterations of the workload (same batches, same injected noise, reference
+    schedule) through the engine's call-by-call API and through the oracle; max abs difference of the reported scalars
+    and of the parameters afterwards.  Part of the baseline leg: the oracle is the checker, never the thing measured."""
+    import numpy as np
+    import torch
+    import sac_td3_cudagraphs_pytorch_amd as pkg
+    from sac_td3_cudagraphs_pytorch_amd import _lib, schema
+    from oracle.sac_td3_ref import Hps, RefAgent
+    o, a, B, td3 = w["o"], w["a"], w["batch"], w["td3"]
+    hps = (Hps.td3 if td3 else Hps.sac)(batch_size=B)
+    torch.manual_seed(0)
+    lo, hi = [-w["bound"]] * a, [w["bound"]] * a
+    ref = RefAgent(o, a, lo, hi, hps)
+    eng = pkg.Engine(pkg.Config.from_hps(hps, o, a, rb_capacity=1024, seed=0, device_id=device_id), lo, hi)
+    nh = a if td3 else 2 * a
+    flat_a = lambda m: schema.dict_to_flat({k: v for k, v in m.state_dict().items() if k.startswith(("fc_stack", "head"))}, o, nh, True)
+    flat_c = lambda ms: np.concatenate([schema.dict_to_flat(q.state_dict(), o + a, 1, True) for q in ms])
+    eng.set_params(_lib.ACTOR, flat_a(ref.actor)); eng.set_params(_lib.ACTOR_TARGET, flat_a(ref.actor_target))
+    eng.set_params(_lib.CRITICS, flat_c(ref.qnets)); eng.set_params(_lib.CRITICS_TARGET, flat_c(ref.qnets_target))
+    g = torch.Generator().manual_seed(1)
+    worst = {}
+    for i in range(iters):
+        obs, nobs = torch.randn(B, o, generator=g), torch.randn(B, o, generator=g)
+        act = (torch.rand(B, a, generator=g) * 2 - 1) * w["bound"]
+        rew, done = torch.randn(B, generator=g), torch.rand(B, generator=g) < 0.01
+        noise = {"critic": torch.randn(B, a, generator=g), "actor": [torch.randn(B, a, generator=g) for _ in range(2)],
+                 "alpha": [torch.randn(B, a, generator=g) for _ in range(2)]}
+        want = ref.iteration(ref.to_batch(obs, act, rew, nobs, done), i, noise)
+        eng.load_batch(obs, act, rew, nobs, done)
+        eng.set_noise(_lib.SITE_CRITIC, noise["critic"])
+        eng.update_qnets()
+        if i % (hps.actor_update_delay + 1) == 0:
+            for j in range(hps.actor_update_delay):
+                eng.set_noise(_lib.SITE_ACTOR0, noise["actor"][j]); eng.set_noise(_lib.SITE_ALPHA0, noise["alpha"][j])
+                eng.update_actor()
+        eng.update_targ_nets(i + 1)
+        got = eng.read_metrics()
+        for k, v in want.items():
+            worst[k] = max(worst.get(k, 0.0), abs(got[k] - float(v)))
+    worst["params/critics"] = float(np.abs(eng.get_params(_lib.CRITICS) - flat_c(ref.qnets)).max())
+    worst["params/actor"] = float(np.abs(eng.get_params(_lib.ACTOR) - flat_a(ref.actor)).max())
+    eng.close()
+    return {"iterations": iters, "max_abs_delta": worst,
+            "note": "fp32 vs the plain-PyTorch oracle on the same batches and noise; parameters after the Adam steps can differ by "
+                    "up to 2 lr per step where a gradient is near zero (sign-like first steps), see tests/helpers.py"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +208,8 @@ def main():
                                    f"{w['rows']} rows resident in a {w['capacity']}-row HBM replay ring, "
                                    "one hipGraph launch per iteration (1 critic update, 2 actor+alpha updates every 3rd, Polyak)",
                        "parallelism": f"{world} independent seeds, one per GPU, no collective"},
+            # one iteration = 1 critic update (+ Polyak) and, every 3rd iteration, 2 actor(+alpha) updates
+            "critic_updates_per_s": world * args.steps / dt, "actor_updates_per_s": world * args.steps / dt * 2.0 / 3.0,
             "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
             "final_metrics": metrics,
         }
@@ -224,6 +274,7 @@ def main():
             out["cpu_baseline"] = {"value": best[0], "unit": "gradient-steps/s", "cores": best[2], "kind": "port",
                                    "sample": f"{best[1]} iterations of the same workload through oracle/sac_td3_ref.py "
                                              f"(plain PyTorch CPU eager, torch.set_num_threads({best[2]}); faster of 1 and 8 threads)"}
+            out["parity"] = parity_deltas(w, local)
             v, n = oracle_rate(w, "cuda", 6.0)
             out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
                                           "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
