@@ -166,6 +166,8 @@ static GatherArgs gather_args(sactd3_engine* e, const float* ring, int identity_
   g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
   g.B = e->B; g.len_override = identity_len;
   g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)e->B * e->rec4 + 1);
+  const long chunks = (long)e->B * e->rec4;
+  g.cpb = (int)((chunks + 256L * gather_blocks(chunks) - 1) / (256L * gather_blocks(chunks)));
   return g;
 }
 template <int PRO, bool F1, int C1>
@@ -1129,6 +1131,7 @@ int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec
     g.X = (float4*)X; g.Xn = (float4*)Xn; g.rew = rw; g.done = dn; g.B = batch; g.len_override = -1;
     g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)batch * e->rec4 + 1);
     const dim3 grid(gather_blocks((long)batch * e->rec4));
+    g.cpb = (int)(((long)batch * e->rec4 + 256L * grid.x - 1) / (256L * grid.x));
     hipEvent_t t0, t1;
     hipEventCreate(&t0); hipEventCreate(&t1);
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, e->stream, g);

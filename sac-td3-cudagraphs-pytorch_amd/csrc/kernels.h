@@ -227,34 +227,41 @@ struct GatherArgs {
   float* rew; float* done;
   int B; int len_override;                // len_override >= 0: use it instead of ctl->rb_len (staged batches)
   unsigned rec4_magic;                    // ceil(2^32 / rec4) when B * rec4 * rec4 < 2^32, else 0
+  int cpb;                                // chunks per thread = ceil(B * rec4 / (256 * blocks of the launch)), <= GATHER_CPT
 };
 
+#ifndef GATHER_CPT
 #define GATHER_CPT 4    // float4 chunks per thread: loads in flight per lane
-__device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block, unsigned nblocks) {
+#endif
+// A block moves a CONTIGUOUS span of cpb * 256 chunks (cpb <= GATHER_CPT, chosen by the host with the grid) = a handful of
+// records.  Their ring indices are drawn once per record into LDS (Philox is ~150 instructions: drawn per chunk, as a
+// one-pass kernel would, the 196 chunks of a Humanoid record made the kernel ALU-bound at half of the copy rate).
+__device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block) {
+  __shared__ int ids_s[GATHER_CPT * 256 + 2];
   // one batch of requests for the sampling state (a field read behind a branch on another field is a second round trip)
   const int inject = p.ctl->inject_idx, rb_len = p.ctl->rb_len, ctr = p.ctl->sample_ctr;
   const unsigned long long seed = p.ctl->seed;
   const int len = p.len_override >= 0 ? p.len_override : rb_len;
-  const unsigned g0 = block * 256u + threadIdx.x;
-  const unsigned total = (unsigned)p.B * (unsigned)p.rec4, stride = nblocks * 256u;   // host guarantees B * rec4 < 2^31
+  const unsigned total = (unsigned)p.B * (unsigned)p.rec4;             // host guarantees B * rec4 < 2^31
+  const unsigned c0 = block * (unsigned)p.cpb * 256u;
+  if (c0 >= total) return;                                             // (block-uniform)
+  const unsigned c1 = min(c0 + (unsigned)p.cpb * 256u, total);
+  const unsigned r0 = fast_div(c0, (unsigned)p.rec4, p.rec4_magic), r1 = fast_div(c1 - 1u, (unsigned)p.rec4, p.rec4_magic);
+  for (unsigned i = threadIdx.x; i <= r1 - r0; i += 256u)
+    ids_s[i] = inject ? p.idx[r0 + i] : (int)philox_index(seed, (unsigned)ctr, r0 + i, (unsigned)len);
+  __syncthreads();
   int bb[GATHER_CPT], cc[GATHER_CPT], ids[GATHER_CPT]; float4 v[GATHER_CPT]; bool on[GATHER_CPT], first[GATHER_CPT];
   // All loads first, all stores afterwards: a store that may alias a later load makes the compiler drain the memory
   // queue (s_waitcnt vmcnt(0)) in between, which would serialise the record fetches.
 #pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) {            // consecutive threads -> consecutive chunks of a record
-    const unsigned g = g0 + u * stride;
-    on[u] = g < total;
-    const unsigned q = on[u] ? fast_div(g, (unsigned)p.rec4, p.rec4_magic) : 0u;
+    const unsigned g = c0 + (unsigned)u * 256u + threadIdx.x;
+    on[u] = u < p.cpb && g < c1;
+    const unsigned q = on[u] ? fast_div(g, (unsigned)p.rec4, p.rec4_magic) : r0;
     bb[u] = (int)q; cc[u] = on[u] ? (int)(g - q * (unsigned)p.rec4) : 0;
+    ids[u] = ids_s[q - r0];
     first[u] = !inject && on[u] && cc[u] == 0;
     on[u] = on[u] && cc[u] <= p.cx + p.cn;           // trailing pad chunk(s) are not moved
-  }
-  if (inject) {
-#pragma unroll
-    for (int u = 0; u < GATHER_CPT; ++u) ids[u] = p.idx[bb[u]];
-  } else {
-#pragma unroll
-    for (int u = 0; u < GATHER_CPT; ++u) ids[u] = (int)philox_index(seed, (unsigned)ctr, (unsigned)bb[u], (unsigned)len);
   }
 #pragma unroll
   for (int u = 0; u < GATHER_CPT; ++u) v[u] = p.ring[(long)ids[u] * p.rec4 + (on[u] ? cc[u] : 0)];
@@ -268,7 +275,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block,
     else { p.rew[b] = v[u].x; p.done[b] = v[u].y; }
   }
 }
-__global__ __launch_bounds__(256) void k_gather(GatherArgs p) { gather_body(p, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_gather(GatherArgs p) { gather_body(p, blockIdx.x); }
 
 __global__ void k_tick(int* a, int* b) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { if (a) *a += 1; if (b) *b += 1; }
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
   if (FUSE1 && p.gblocks && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: these blocks are the replay gather
-    gather_body(p.ga, blockIdx.x - p.nt_blocks, (unsigned)p.gblocks);
+    gather_body(p.ga, blockIdx.x - p.nt_blocks);
     return;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;

@@ -1,6 +1,6 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for v in ("base", "cpt2", "cpt8", "nt", "cpt8nt"):
+for v in sys.argv[1:] or ("base", "cpt2", "cpt8"):
     env = dict(os.environ, SACTD3_LIBRARY=os.path.join(ROOT, "tools", "libs", f"lib_{v}.so"))
     res = []
     for b in (1024, 16384, 65536):
