@@ -22,6 +22,32 @@ def shard_seeds(num_seeds: int, world_size: int, rank: int, first_seed: int = 0)
     return [first_seed + s for s in range(num_seeds) if s % world_size == rank]
 
 
+# The reference's sweep unit (spawner.py:21-38,147-178): an "environment bundle" names a list of tasks and a run is one job
+# per (task, seed), tasks outermost.  Only the enumeration and its mapping onto GPUs are restated here -- the cluster side
+# of spawner.py (SLURM / tmux scripts, wandb) is out of scope.
+ENV_BUNDLES = {
+    "debug": ["Hopper-v4"],
+    "low": ["Hopper-v4", "Pusher-v4"],
+    "medium": ["HalfCheetah-v4", "Walker2d-v4", "Ant-v4"],
+    "high": ["Humanoid-v4", "HumanoidStandup-v4"],
+}
+
+
+def sweep_jobs(env_bundle: str, num_seeds: int) -> List[Tuple[str, int]]:
+    """[(env_id, seed)] in the reference's job order: for env in bundle: for seed in range(num_seeds)."""
+    if env_bundle not in ENV_BUNDLES:
+        raise ValueError(f"unknown env bundle {env_bundle!r} (one of {sorted(ENV_BUNDLES)})")
+    if num_seeds < 1:
+        raise ValueError("num_seeds must be positive")
+    return [(env, seed) for env in ENV_BUNDLES[env_bundle] for seed in range(num_seeds)]
+
+
+def shard_jobs(jobs: List[Tuple[str, int]], world_size: int, rank: int) -> List[Tuple[str, int]]:
+    """This rank's share of a sweep: job k runs on GPU k mod world_size (one learner per GPU at a time, in order)."""
+    assert 0 <= rank < world_size
+    return [j for k, j in enumerate(jobs) if k % world_size == rank]
+
+
 def init_process_group(backend: str = "nccl"):
     """Join the job's process group (nccl == RCCL on ROCm; gloo for CPU rehearsals).  Returns the module or None."""
     rank, world, local = rank_info()

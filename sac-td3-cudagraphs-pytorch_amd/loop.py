@@ -4,6 +4,8 @@ be driven end to end without tensordict / torchrl / gymnasium being importable:
   segment()     rollout generator                      orchestrator.py:42-118   
   train()       the training loop's control flow       orchestrator.py:317-352 (+ counters :326,342,349)
   episode()     evaluation-episode generator           orchestrator.py:121-246 (lengths / returns only)
+  Evaluator     the eval block of the loop             orchestrator.py:303-305,354-403 (rolling window, best model, speed)
+  Tabular       key/value progress files               helpers/logger.py:93-150 (progress.json lines, progress.csv, text table)
 
 `env` is anything with gymnasium's vector-env protocol as the reference uses it: `reset(seed=) -> (obs[n, o], info)`,
 `step(actions[n, a]) -> (next_obs, rewards[n], terminations[n], truncations[n], infos)` with autoreset and
@@ -13,7 +15,11 @@ be driven end to end without tensordict / torchrl / gymnasium being importable:
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, Generator, Optional
+import json
+import time
+from collections import deque
+from pathlib import Path
+from typing import Any, Callable, Dict, Generator, Optional, TextIO
 
 import numpy as np
 
@@ -58,15 +64,19 @@ def segment(env, agent, seed: int, segment_len: int, learning_starts: int, actio
         r += 1
 
 
-def train(cfg: Any, env, agent, *, fused: bool = True, on_eval: Optional[Callable[[Any, int], None]] = None) -> Dict[str, float]:
+def train(cfg: Any, env, agent, *, fused: bool = True, on_eval: Optional[Callable[[Any, int], None]] = None,
+          evaluator: Optional["Evaluator"] = None) -> Dict[str, float]:
     """Control flow of orchestrator.py:317-352 (no wandb / tqdm / checkpoint upload): interact, count, wait for
     `learning_starts`, then per iteration sample -> critic update -> (every delay+1 iterations) delay x actor
     update -> target update, with the reference's counters.  `fused=True` issues the whole iteration as one graph
-    launch (Agent.iteration); `fused=False` makes the reference's individual calls.  Returns the last metrics."""
+    launch (Agent.iteration); `fused=False` makes the reference's individual calls.  Every `eval_every` timesteps
+    `evaluator` (the reference's eval block, :354-403) and/or `on_eval` run.  Returns the last metrics."""
     seg_gen = segment(env, agent, cfg.seed, cfg.segment_len, cfg.learning_starts, cfg.action_repeat)
     i = 0
     tlog: Dict[str, Any] = {}
     while agent.timesteps_so_far <= cfg.num_timesteps:
+        if evaluator is not None:
+            evaluator.maybe_start_clock(agent.timesteps_so_far)           # orchestrator.py:319-322
         next(seg_gen)
         agent.timesteps_so_far += cfg.segment_len * cfg.num_envs
         if agent.timesteps_so_far <= cfg.learning_starts:
@@ -83,10 +93,112 @@ def train(cfg: Any, env, agent, *, fused: bool = True, on_eval: Optional[Callabl
                     tlog.update(agent.update_actor(batch))
                     agent.actor_updates_so_far += 1
             agent.update_targ_nets()
-        if on_eval is not None and agent.timesteps_so_far % cfg.eval_every == 0:
-            on_eval(agent, agent.timesteps_so_far)
+        if agent.timesteps_so_far % cfg.eval_every == 0:
+            if evaluator is not None:
+                evaluator(agent)
+            if on_eval is not None:
+                on_eval(agent, agent.timesteps_so_far)
         i += 1
     return agent.engine.read_metrics()
+
+
+class Tabular:
+    """Key/value progress writer with the file formats of the reference's logger (helpers/logger.py:93-150):
+    `progress.json` holds one JSON object per dump, `progress.csv` one row per dump under a header that grows when a
+    new key appears (earlier rows are padded), and an optional text stream gets a boxed two-column table."""
+
+    def __init__(self, directory: Optional[Path] = None, stream: Optional[TextIO] = None, suffix: str = ""):
+        self._kv: Dict[str, Any] = {}
+        self._keys: list = []
+        self._rows: list = []
+        self._stream = stream
+        self._json = self._csv = None
+        if directory is not None:
+            directory = Path(directory)
+            directory.mkdir(parents=True, exist_ok=True)
+            self._json = (directory / f"progress{suffix}.json").open("wt")
+            self._csv = directory / f"progress{suffix}.csv"
+
+    def record(self, key: str, val: Any) -> None:
+        self._kv[key] = val.item() if isinstance(val, np.ndarray) and val.ndim == 0 else (float(val) if isinstance(val, np.floating) else val)
+
+    def dump(self) -> Dict[str, Any]:
+        kv, self._kv = self._kv, {}
+        if not kv:
+            return kv
+        if self._json is not None:
+            self._json.write(json.dumps(kv) + "\n")
+            self._json.flush()
+        if self._csv is not None:
+            self._keys += [k for k in kv if k not in self._keys]
+            self._rows.append(kv)
+            with self._csv.open("wt") as f:            # a new column rewrites the (small) file, as the reference's writer does
+                f.write(",".join(self._keys) + "\n")
+                for row in self._rows:
+                    f.write(",".join("" if row.get(k) is None else str(row[k]) for k in self._keys) + "\n")
+        if self._stream is not None:
+            cells = {k[:40]: (f"{v:<8.3g}" if isinstance(v, float) else str(v))[:40] for k, v in kv.items()}
+            kw, vw = max(map(len, cells)), max(map(len, cells.values()))
+            bar = "-" * (kw + vw + 7)
+            self._stream.write("\n".join([bar] + [f"| {k.ljust(kw)} | {v.ljust(vw)} |" for k, v in cells.items()] + [bar]) + "\n")
+            self._stream.flush()
+        return kv
+
+    def close(self) -> None:
+        if self._json is not None:
+            self._json.close()
+
+
+class Evaluator:
+    """The evaluation block of the training loop (orchestrator.py:354-403): every call plays `eval_steps` greedy
+    episodes, reports the mean length / return over a rolling window of the last 20 x eval_steps episodes (:303-305,
+    :364-367), saves the model as `ckpt_best` when the windowed return improves (:376-380) and computes the training speed
+    in env steps per second with evaluation time excluded and a burn-in before the clock starts (:319-322,:392-397)."""
+
+    def __init__(self, cfg: Any, eval_env, agent, tabular: Optional[Tabular] = None, ckpt_dir: Optional[Path] = None,
+                 clock: Callable[[], float] = time.time):
+        self.cfg, self.tabular, self.ckpt_dir, self._clock = cfg, tabular, ckpt_dir, clock
+        self.ep_gen = episode(eval_env, agent, cfg.seed)
+        window = 20 * cfg.eval_steps
+        self.len_buff, self.ret_buff = deque(maxlen=window), deque(maxlen=window)
+        self.start_time: Optional[float] = None
+        self.burnin_ts: Optional[int] = None
+        self.time_spent_eval = 0.0
+        self.history: list = []
+
+    def maybe_start_clock(self, timesteps_so_far: int) -> None:
+        burn = getattr(self.cfg, "measure_burnin", 0)
+        if self.start_time is None and timesteps_so_far >= burn + self.cfg.learning_starts:
+            self.start_time, self.burnin_ts = self._clock(), timesteps_so_far
+
+    def __call__(self, agent) -> Dict[str, float]:
+        t0 = self._clock()
+        for _ in range(self.cfg.eval_steps):
+            ep = next(self.ep_gen)
+            self.len_buff.append(float(ep["length"]))
+            self.ret_buff.append(float(ep["return"]))
+        out = {"timestep": int(agent.timesteps_so_far), "length": float(np.mean(np.asarray(self.len_buff, np.float32))),
+               "return": float(np.mean(np.asarray(self.ret_buff, np.float32)))}
+        if self.tabular is not None:
+            for k, v in out.items():
+                self.tabular.record(k, v)
+        if out["return"] > agent.best_eval_ep_ret:
+            agent.best_eval_ep_ret = out["return"]
+            if self.ckpt_dir is not None:
+                Path(self.ckpt_dir).mkdir(parents=True, exist_ok=True)
+                agent.save(self.ckpt_dir, sfx="best")
+            out["new_best"] = True
+        out["replay_buffer_numel"] = len(agent.rb) if getattr(agent, "rb", None) is not None else 0
+        self.time_spent_eval += self._clock() - t0
+        if self.start_time is not None:
+            train_time = self._clock() - self.start_time - self.time_spent_eval
+            out["speed"] = (agent.timesteps_so_far - self.burnin_ts) / max(train_time, 1e-9)
+            if self.tabular is not None:
+                self.tabular.record("speed", out["speed"])
+        if self.tabular is not None:
+            self.tabular.dump()
+        self.history.append(out)
+        return out
 
 
 def episode(env, agent, seed: int) -> Generator[Dict[str, np.ndarray], None, None]:

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the seed-parallel launcher's sharding, barrier and timing aggregation (the N > 1
 path of bench.py).  Replicas only: no tensor of the learners ever crosses ranks."""
 import os
+import pytest
 import socket
 
 import torch
@@ -83,3 +84,14 @@ def test_shared_replay_variant_keeps_all_rings_identical():
     assert n0 == n1 == 12 and obs0 == obs1 and d0 == d1                 # every ring holds every rank's rows, same order
     assert obs0[:4] == [0.0, 0.0, 100.0, 100.0] and obs0[4:8] == [10.0, 10.0, 110.0, 110.0]
     assert d0[:4] == [False, False, True, False]                        # rank 1's termination flag travelled with its row
+
+
+def test_sweep_enumeration_and_gpu_assignment():
+    """spawner.py:147-178: one job per (env, seed), envs outermost; here job k goes to GPU k mod N."""
+    jobs = launcher.sweep_jobs("medium", 3)
+    assert jobs[:4] == [("HalfCheetah-v4", 0), ("HalfCheetah-v4", 1), ("HalfCheetah-v4", 2), ("Walker2d-v4", 0)] and len(jobs) == 9
+    shards = [launcher.shard_jobs(jobs, 8, r) for r in range(8)]
+    assert sorted(j for s in shards for j in s) == sorted(jobs) and [len(s) for s in shards] == [2, 1, 1, 1, 1, 1, 1, 1]
+    assert launcher.shard_jobs(launcher.sweep_jobs("debug", 8), 8, 5) == [("Hopper-v4", 5)]      # the 8-seed node of BASELINE.json
+    with pytest.raises(ValueError):
+        launcher.sweep_jobs("nope", 1)

@@ -60,7 +60,7 @@ def test_truncation_stores_the_final_observation_not_the_reset_one():
 
 
 @pytest.mark.gpu
-def test_train_loop_drives_the_engine_end_to_end():
+def test_train_loop_drives_the_engine_end_to_end(tmp_path):
     import torch
     import sac_td3_cudagraphs_pytorch_amd as P
     from oracle.sac_td3_ref import Hps
@@ -75,7 +75,12 @@ def test_train_loop_drives_the_engine_end_to_end():
         agent = P.Agent({"ob_shape": (n, o), "ac_shape": (n, a)}, np.full(a, -1.0, np.float32), np.full(a, 1.0, np.float32),
                         torch.device("cuda:0"), cfg, P.ReplayBuffer(cfg.rb_capacity))
         evals = []
-        m = loop.train(cfg, env, agent, fused=fused, on_eval=lambda ag, ts: evals.append(ts))
+        cfg.eval_steps, cfg.measure_burnin = 2, 0
+        ev = loop.Evaluator(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=20), agent, loop.Tabular(tmp_path / str(fused)),
+                            ckpt_dir=tmp_path / str(fused))
+        m = loop.train(cfg, env, agent, fused=fused, on_eval=lambda ag, ts: evals.append(ts), evaluator=ev)
+        assert [h["timestep"] for h in ev.history] == [800, 1600, 2400] and ev.history[0]["new_best"] and ev.history[-1]["speed"] > 0
+        assert (tmp_path / str(fused) / "ckpt_best.pth").exists() and len((tmp_path / str(fused) / "progress.csv").read_text().splitlines()) == 4
         assert agent.timesteps_so_far == 2404 and len(agent.rb) == 2404
         assert agent.qnet_updates_so_far == 501            # iterations after learning_starts (orchestrator.py:329-342)
         assert agent.actor_updates_so_far == 2 * 167       # i % 3 == 0 on the global iteration counter (:345-349)
@@ -85,3 +90,64 @@ def test_train_loop_drives_the_engine_end_to_end():
         logs.append((m, agent.engine.get_params(0)))
     # same seeds, same Philox streams, same kernels: the fused and the call-by-call loops are the same computation
     assert logs[0][0] == logs[1][0] and np.array_equal(logs[0][1], logs[1][1])
+
+
+class _StubAgent:
+    """Duck-typed stand-in of the Agent for the host-side harness tests (no GPU): a fixed linear policy."""
+
+    def __init__(self, a, gain):
+        self.a, self.gain = a, gain
+        self.timesteps_so_far, self.best_eval_ep_ret, self.saved, self.rb = 0, -np.inf, [], [0] * 7
+
+    def predict(self, td, explore):
+        assert explore is False                           # evaluation acts greedily (orchestrator.py:165-173)
+        ob = np.asarray(td["observations"], np.float32)
+        return np.clip(-self.gain * ob[:, :self.a], -1, 1)
+
+    def save(self, path, sfx=None):
+        self.saved.append((str(path), sfx, self.best_eval_ep_ret))
+
+
+def test_tabular_writes_json_lines_and_a_growing_csv(tmp_path):
+    import io
+    import json
+    stream = io.StringIO()
+    tab = loop.Tabular(tmp_path, stream)
+    tab.record("timestep", 800); tab.record("return", np.array(-3.5, np.float32)); tab.dump()
+    tab.record("timestep", 1600); tab.record("return", -2.0); tab.record("speed", 1234.5); tab.dump()
+    assert tab.dump() == {}                               # nothing recorded: nothing written
+    tab.close()
+    lines = [json.loads(x) for x in (tmp_path / "progress.json").read_text().splitlines()]
+    assert lines == [{"timestep": 800, "return": -3.5}, {"timestep": 1600, "return": -2.0, "speed": 1234.5}]
+    rows = (tmp_path / "progress.csv").read_text().splitlines()
+    assert rows[0] == "timestep,return,speed" and rows[1] == "800,-3.5," and rows[2] == "1600,-2.0,1234.5"
+    text = stream.getvalue().splitlines()
+    assert text[0].startswith("---") and "| timestep | 800" in text[1] and text.count(text[0]) == 4
+
+
+def test_evaluator_window_best_model_and_speed(tmp_path):
+    o, a = 6, 2
+    cfg = SimpleNamespace(seed=3, eval_steps=2, learning_starts=100, measure_burnin=50)
+    now = [1000.0]
+    agent = _StubAgent(a, gain=0.0)
+    ev = loop.Evaluator(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=10), agent, loop.Tabular(tmp_path), ckpt_dir=tmp_path / "ck",
+                        clock=lambda: now[0])
+    ev.maybe_start_clock(120)
+    assert ev.start_time is None                          # before learning_starts + measure_burnin (orchestrator.py:319-322)
+    ev.maybe_start_clock(152); ev.maybe_start_clock(999)
+    assert (ev.start_time, ev.burnin_ts) == (1000.0, 152)
+    agent.timesteps_so_far = 952
+    now[0] = 1010.0                                       # 10 s of training so far
+    r1 = ev(agent)
+    assert r1["timestep"] == 952 and r1["new_best"] and agent.saved == [(str(tmp_path / "ck"), "best", r1["return"])]
+    assert r1["speed"] == pytest.approx((952 - 152) / 10.0) and r1["replay_buffer_numel"] == 7
+    assert len(ev.ret_buff) == 2 and r1["length"] <= 10
+    agent.gain = 5.0                                      # a worse (saturating) policy: the windowed mean must not improve
+    for _ in range(25):
+        ev(agent)
+    assert len(ev.ret_buff) == 40 and len(ev.len_buff) == 40          # rolling window of 20 x eval_steps episodes
+    assert agent.best_eval_ep_ret == max(h["return"] for h in ev.history)
+    assert len(agent.saved) == sum(1 for h in ev.history if h.get("new_best"))
+    import json
+    rows = [json.loads(x) for x in (tmp_path / "progress.json").read_text().splitlines()]
+    assert len(rows) == 26 and list(rows[0]) == ["timestep", "length", "return", "speed"]
