@@ -246,6 +246,15 @@ def main():
             eng.rb_extend(*rows)
         eng.sync()
         out["rb_extend_call_us"] = (time.perf_counter() - tp) / 300 * 1e6
+        # SURVEY 8(d)'s optional second figure: the loop as orchestrator.py:325-352 runs it, minus the simulator -- per
+        # iteration one synchronous predict for the 4 envs, one rb.extend of their 4 transitions, one fused update
+        tp = time.perf_counter()
+        for i in range(600):
+            eng.predict(ob, True)
+            eng.rb_extend(*rows)
+            eng.step(i % 3 == 0)
+        eng.sync()
+        out["loop_with_acting_per_s"] = 600 / (time.perf_counter() - tp)
         if world == 1 and not args.no_baselines:
             # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
             sweep = {}

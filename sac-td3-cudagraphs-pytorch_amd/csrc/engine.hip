@@ -1005,19 +1005,16 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
     memset(e->h_obs + (size_t)i * e->ldo, 0, sizeof(float) * e->ldo);
     memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
   }
-  HIPCHK(hipMemcpyAsync(e->p_x, e->h_obs, sizeof(float) * (size_t)n * e->ldo, hipMemcpyHostToDevice, e->stream));
+  // The kernels read the observations from, and write the actions to, the pinned host buffers themselves (a few hundred
+  // bytes over the host link): two kernels and one synchronisation per call, no copy commands, no separate counter kernel.
   {
-    const TrunkGrp g{e->p_x, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
+    const TrunkGrp g{e->h_obs, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
     RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
   }
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
-  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->p_act, e->a4, 0, nullptr);
+  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr);
+  if (explore) t.tick = &e->ctl->predict_ctr;
   RCCHK(launch_tail(e, e->stream, t));
-  if (explore) {
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipMemcpyAsync(e->h_act, e->p_act, sizeof(float) * (size_t)n * e->a4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int i = 0; i < n; ++i) memcpy(actions + (size_t)i * e->a, e->h_act + (size_t)i * e->a4, sizeof(float) * e->a);
   return 0;
