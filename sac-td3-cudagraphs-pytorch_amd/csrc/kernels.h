@@ -1,10 +1,12 @@
 // Device code of the SAC/TD3 update engine for gfx950 (MI355X, CDNA4).  wave = 64 lanes throughout.
 //
 // The whole path is latency-bound (B <= 4096 rows, 256-wide layers: everything lives in the Infinity Cache), so every
-// kernel is built the same way: issue ALL of its global loads first (one memory round trip), compute out of
-// registers / LDS, reduce with DPP (no ds_bpermute), never index a local array dynamically (that is scratch memory).
+// kernel is built the same way: issue ALL of its global loads first (one memory round trip; unconditional, address-
+// clamped and masked with selects -- see ld4_cols / PIN for what makes the compiler serialise them otherwise), compute
+// out of registers / LDS, reduce with DPP (no ds_bpermute), store last, never index a local array dynamically (that is
+// scratch memory).
 //
-//   k_gather          replay ring -> batch slot (float4 record chunks, Philox index draw fused)
+//   k_gather          replay ring -> batch slot (float4 record chunks; Philox index drawn once per record into LDS)
 //   k_nt / k_nt_wide  Y = pro(A) W^T + b on v_mfma_f32_16x16x4_f32; pro = LayerNorm+ReLU of the producing layer applied to
 //                     the A fragments in registers; optionally the FIRST layer (x W1^T + b1) is computed in the same kernel
 //                     straight into those fragments (narrow inputs); W tiles parked in LDS, block shape picked per launch
@@ -608,7 +610,8 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
 // fetched once per block with full-line loads) with the LayerNorm+ReLU between them as a row kernel of its own.
 // 8 waves per block, two per SIMD (wave = 16 rows x 32 columns): a SIMD issues its waves in order, so with a single
 // wave the LDS fragment reads, the parking of the next chunk and the barrier all sit in front of the MFMAs; a second
-// wave fills those gaps (measured at B = 1024, K = 256: 4000 -> see DESIGN.md cycles per 64-wide chunk, MFMA alone is 2048).
+// wave fills those gaps (measured at B = 1024, K = 256: 4000 -> 3500 cycles per 64-wide chunk; MFMA issue alone is 2048,
+// the rest is the 32 KB each CU has to pull per chunk).
 #define KC64 64
 #define LS64 (KC64 + 4)
 __global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
