@@ -37,7 +37,7 @@ def make_engine(w, seed, device_id):
     from sac_td3_cudagraphs_pytorch_amd import schema
     cfg = pkg.Config(ob_dim=w["o"], ac_dim=w["a"], batch_size=w["batch"], rb_capacity=w["capacity"], max_envs=4,
                      prefer_td3_over_sac=w["td3"], bcq_style_targ_mix=w["td3"], qnets_lr=3e-4 if w["td3"] else 1e-3,
-                     seed=seed, device_id=device_id)
+                     seed=seed, device_id=device_id, use_graphs=os.environ.get("SACTD3_BENCH_GRAPHS", "1") != "0")   # (0: same launches, no hipGraph)
     eng = pkg.Engine(cfg, [-w["bound"]] * w["a"], [w["bound"]] * w["a"])
     torch.manual_seed(seed)  # reference init (agents/nets.py:34-49) under the run's seed
     actor, critics = schema.reference_initial_params(w["o"], w["a"], w["td3"], True)
