@@ -220,7 +220,7 @@ def main():
         out["roofline"] = {"kernel": "k_gather", "bound": "hbm", "achieved": ab / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ab / us * 1e-3 / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": ab, "avg_launch_us": us,
                            "note": "B=256 is launch/latency-bound by construction; see gather_batch_sweep for the bandwidth end "
-                                   "and profiles/r01_gather_humanoid_b65536_pmc.csv for the PMC traffic (1.04x algorithmic)"}
+                                   "and profiles/r01_gather_humanoid_b65536_pmc.csv for the PMC traffic (1.01x algorithmic)"}
         # the kernel that takes the most time: hidden layers of the 4 critics (fp32 MFMA); FLOPs = 2*MAC of both layers
         us_t = eng.time_kernel("trunk_critics", 500)
         fl = 4 * 2.0 * w["batch"] * 256 * ((w["o"] + w["a"]) + 256)
@@ -271,7 +271,7 @@ def main():
             out["replay_gather_hbm"] = {"record": "Humanoid-v4 (o=376, a=17), 1M-row ring", "rows_per_launch": 65536, "us": us_h,
                                         "algo_bytes": by_h, "achieved": by_h / us_h * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": by_h / us_h * 1e-3 / HBM_PEAK_GBS,
-                                        "traffic": "422 MB per launch from FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_gather_humanoid_b65536_pmc.csv) = 1.04x algorithmic"}
+                                        "traffic": "410 MB per launch from FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_gather_humanoid_b65536_pmc.csv) = 1.01x algorithmic"}
             eh.close()
             # the op sizes are tiny: torch's default of one thread per host core (128 here) is slower than a few threads,
             # so time 1 and 8 threads on a bounded sample each and report the faster one
