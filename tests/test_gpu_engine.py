@@ -131,6 +131,36 @@ def test_native_index_stream_matches_philox_oracle():
         assert np.array_equal(got["next_observations"], nobs[want_idx])
 
 
+def test_full_size_ring_properties():
+    """BASELINE config 4 at full size (Humanoid-v4 records, 1 000 000 rows = 3.1 GB of HBM, B = 1024), where the ring cannot
+    be mirrored on the host: size-independent properties instead.  (i) the native index stream is the Philox oracle's,
+    in range; (ii) sampling is idempotent: gathering the SAME indices again (injected) returns bit-identical rows, and a
+    row drawn twice inside one batch is identical both times; (iii) rows written by rb_extend at the wrap-around edge of
+    a full ring come back bit-exact and the length saturates at the capacity."""
+    o, a, bound = DIMS["humanoid"]
+    B, cap, seed = 1024, 1_000_000, 77
+    eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=cap, seed=seed), [-bound] * a, [bound] * a)
+    eng.rb_fill_synthetic(cap - 3, seed=5)
+    assert eng.rb_len() == cap - 3
+    obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(8, o, a, bound, seed=6)]
+    eng.rb_extend(obs, act, rew, nobs, done)             # rows cap-3 .. cap-1, then wraps onto rows 0 .. 4
+    assert eng.rb_len() == cap
+    eng.rb_sample()
+    first = eng.read_batch()
+    want_idx = replay_ref.sample_indices(seed, 0, B, cap)
+    assert np.array_equal(first["index"], want_idx) and first["index"].min() >= 0 and first["index"].max() < cap
+    eng.rb_sample_with_indices(first["index"])
+    again = eng.read_batch()
+    for k in first:
+        assert np.array_equal(first[k], again[k]), k
+    probe = np.concatenate([np.arange(cap - 3, cap), np.arange(0, 5), np.full(B - 8, cap - 1)])
+    eng.rb_sample_with_indices(probe)
+    got = eng.read_batch()
+    assert np.array_equal(got["observations"][:8], obs) and np.array_equal(got["next_observations"][:8], nobs)
+    assert np.array_equal(got["actions"][:8], act) and np.array_equal(got["rewards"][:8], rew) and np.array_equal(got["dones"][:8], done)
+    assert np.array_equal(got["observations"][8:], np.broadcast_to(obs[2], (B - 8, o)))      # the same row, 1016 times over
+
+
 def test_synthetic_fill_statistics():
     o, a, bound = DIMS["humanoid"]
     B = 1024
