@@ -256,6 +256,33 @@ def main():
         eng.sync()
         out["loop_with_acting_per_s"] = 600 / (time.perf_counter() - tp)
         if world == 1 and not args.no_baselines:
+            # Seed sweeps are the reference's unit of work (spawner.py: one job per seed) and one learner leaves most of an
+            # MI355X idle: S independent engines (own stream, own graphs, seeds 0..S-1) in this process, one host thread each,
+            # aggregate gradient-steps/s.  An extra figure -- `value` above stays the one-learner-per-GPU number.
+            multi = {}
+            for S in (2, 4, 8):
+                engs = [eng] + [make_engine(w, seed=100 + k, device_id=local) for k in range(1, S)]
+                for i in range(150):
+                    for e2 in engs:
+                        e2.step(i % 3 == 0)
+                for e2 in engs:
+                    e2.sync()
+                import threading
+
+                def drive(e2):                              # one host thread per learner (ctypes drops the GIL in the call)
+                    for i in range(600):
+                        e2.step(i % 3 == 0)
+                    e2.sync()
+                th = [threading.Thread(target=drive, args=(e2,)) for e2 in engs]
+                tp = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                multi[str(S)] = S * 600 / (time.perf_counter() - tp)
+                for e2 in engs[1:]:
+                    e2.close()
+            out["learners_per_gpu_aggregate_steps_per_s"] = multi
             # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
             sweep = {}
             for bs in (256, 4096, 65536):
