@@ -251,7 +251,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
     g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
     const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64) * nets));
-    hipLaunchKernelGGL(k_nt64, grid, dim3(512), 0, s, g);
+    hipLaunchKernelGGL((k_nt64<4, 2, 2>), grid, dim3(512), 0, s, g);
     HIPCHK(hipGetLastError());
     LnFwd l{};
     l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
@@ -266,7 +266,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
     h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
     for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
-    hipLaunchKernelGGL(k_nt64, grid, dim3(512), 0, s, h2);
+    hipLaunchKernelGGL((k_nt64<4, 2, 2>), grid, dim3(512), 0, s, h2);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -286,7 +286,11 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
   for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
   g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
-  RCCHK(launch_nt(e, s, 0, false, g, nets));
+  if (M >= BIG_BATCH && M == e->B) {   // large batch, too few nets for 64 x 64 tiles to fill the chip: 32 x 32 LDS-tiled form
+    const dim3 grid((unsigned)(((M + 31) / 32) * (HID / 32) * nets));
+    hipLaunchKernelGGL((k_nt64<2, 2, 1>), grid, dim3(256), 0, s, g);
+    HIPCHK(hipGetLastError());
+  } else RCCHK(launch_nt(e, s, 0, false, g, nets));
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
   return launch_nt(e, s, pro, false, h, nets);

@@ -614,17 +614,24 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
 // the rest is the 32 KB each CU has to pull per chunk).
 #define KC64 64
 #define LS64 (KC64 + 4)
-__global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
-  __shared__ __attribute__((aligned(16))) float As[2][64 * LS64];
-  __shared__ __attribute__((aligned(16))) float Ws[2][64 * LS64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave & 3, wn = wave >> 2;
+// WM x WN waves, each 16 rows x (16 TT) columns: <4, 2, 2> is the 64 x 64 tile of the multi-net launches (512 threads),
+// <2, 2, 1> a 32 x 32 tile (256 threads) for a single net's wide first layer, where 64 x 64 tiles would leave 3/4 of the
+// CUs without a block.  Each thread stages 2 float4 of A and 2 of W per 64-wide chunk in both shapes.
+template <int WM, int WN, int TT>
+__global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,K] W[N,K]^T + bias
+  constexpr int TM = 16 * WM, TN = 16 * TT * WN, NTH = 64 * WM * WN;
+  constexpr int RA = 16 * TM / NTH, RW = 16 * TN / NTH, SR = NTH / 16;    // float4 per thread per chunk, rows per staging pass
+  static_assert(RA >= 1 && RW >= 1 && 16 * TM % NTH == 0 && 16 * TN % NTH == 0, "staging map");
+  __shared__ __attribute__((aligned(16))) float As[2][TM * LS64];
+  __shared__ __attribute__((aligned(16))) float Ws[2][TN * LS64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave % WM, wn = wave / WM;
   const int r = lane & 15, kq = lane >> 4;
   if (blockIdx.x == 0 && t == 0) {
     if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
   // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a contiguous run of tiles (half a net's 16 x 4 tile
   // grid at B = 1024) so that the A-row and W-column tiles its 32 CUs share are fetched into that XCD's L2 once.
-  const int tiles_n = (p.N + 63) >> 6, tiles = tiles_n * ((p.M + 63) >> 6);
+  const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
   int L = blockIdx.x;
   { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }
   const int net = L / tiles, idx = L - net * tiles;
@@ -633,33 +640,35 @@ __global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,
   const float* Pn = G.P + ni * p.p_ns;
   const float* A = G.in + ni * p.in_ns;
   const int bm = idx / tiles_n, bn = idx - bm * tiles_n;
-  const int m0 = bm * 64, n0 = bn * 64;
-  // staging map: thread -> rows (t >> 4) + 32 u, u = 0..1, 16-byte column (t & 15): 64 rows x 64 floats per operand
+  const int m0 = bm * TM, n0 = bn * TN;
+  // staging map: thread -> rows (t >> 4) + SR u, 16-byte column (t & 15): 64 floats of every row per chunk
   const int sr0 = t >> 4, sc = (t & 15) * 4;
-  const float* ap[2]; const float* wp[2];
+  const float* ap[RA]; const float* wp[RW];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    ap[u] = A + (long)min(m0 + sr0 + 32 * u, p.M - 1) * p.ld_in;
-    wp[u] = Pn + p.oW + (long)min(n0 + sr0 + 32 * u, p.N - 1) * p.ldw;
-  }
+  for (int u = 0; u < RA; ++u) ap[u] = A + (long)min(m0 + sr0 + SR * u, p.M - 1) * p.ld_in;
+#pragma unroll
+  for (int u = 0; u < RW; ++u) wp[u] = Pn + p.oW + (long)min(n0 + sr0 + SR * u, p.N - 1) * p.ldw;
   const int Kr = (p.K + 3) & ~3;
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nc = (p.K + KC64 - 1) / KC64;
-  float bias[2];                                  // loaded up front: a load issued among the epilogue's stores would make
+  float bias[TT];                                 // loaded up front: a load issued among the epilogue's stores would make
 #pragma unroll                                    // every store wait for the one before it
-  for (int tt = 0; tt < 2; ++tt) bias[tt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 32 * wn + 16 * tt + r, p.N - 1)] : 0.f;
-  float4 ra[2], rw[2];
+  for (int tt = 0; tt < TT; ++tt) bias[tt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 16 * TT * wn + 16 * tt + r, p.N - 1)] : 0.f;
+  float4 ra[RA], rw[RW];
   auto fetch = [&](int c) {
     const int k = c * KC64 + sc;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { ra[u] = ld4_cols(ap[u], k, p.K, Kr); rw[u] = ld4_cols(wp[u], k, p.K, Kr); }
+    for (int u = 0; u < RA; ++u) ra[u] = ld4_cols(ap[u], k, p.K, Kr);
+#pragma unroll
+    for (int u = 0; u < RW; ++u) rw[u] = ld4_cols(wp[u], k, p.K, Kr);
   };
   auto park = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      st4(As[buf] + (sr0 + 32 * u) * LS64 + sc, ra[u]);
-      st4(Ws[buf] + (sr0 + 32 * u) * LS64 + sc, rw[u]);
-    }
+    for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, ra[u]);
+#pragma unroll
+    for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, rw[u]);
   };
   STAMP(0);
   fetch(0);
@@ -669,16 +678,22 @@ __global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,
     const int buf = c & 1;
     if (c + 1 < nc) fetch(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
     const float* ab = As[buf] + (16 * wm + r) * LS64 + 4 * kq;
-    const float* wb = Ws[buf] + (32 * wn + r) * LS64 + 4 * kq;
+    const float* wb = Ws[buf] + (16 * TT * wn + r) * LS64 + 4 * kq;
 #pragma unroll
     for (int s2 = 0; s2 < KC64 / 16; ++s2) {
-      const float4 a = ld4(ab + 16 * s2), b0 = ld4(wb + 16 * s2), b1 = ld4(wb + 16 * LS64 + 16 * s2);
-      // the two column tiles' accumulators are independent: interleaved, no MFMA waits on its predecessor
-#define MFMA_ROW(c)                                                                     \
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c, b0.c, acc[0], 0, 0, 0);         \
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c, b1.c, acc[1], 0, 0, 0);
-      MFMA_ROW(x) MFMA_ROW(y) MFMA_ROW(z) MFMA_ROW(w)
-#undef MFMA_ROW
+      const float4 a = ld4(ab + 16 * s2);
+      float4 b[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) b[tt] = ld4(wb + 16 * tt * LS64 + 16 * s2);
+      // the column tiles' accumulators are independent: interleaved, no MFMA waits on its predecessor
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[tt].x, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[tt].y, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[tt].z, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[tt].w, acc[tt], 0, 0, 0);
     }
     if (c + 1 < nc) park(buf ^ 1);
     __syncthreads();
@@ -686,8 +701,8 @@ __global__ __launch_bounds__(512) void k_nt64(NtArgs p) {       // Y[M,N] = A[M,
   STAMP(1);
   float* y = G.Y + ni * p.y_ns;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int col = n0 + 32 * wn + 16 * tt + r;
+  for (int tt = 0; tt < TT; ++tt) {
+    const int col = n0 + 16 * TT * wn + 16 * tt + r;
     if (col >= p.N) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -38,7 +38,7 @@ int main() {
     g.npg = nets; g.oW = 0; g.ldw = K == 393 ? 400 : 256; g.oBias = 256 * 400; g.p_ns = pn; g.ld_in = g.ldw; g.in_ns = (long)M * g.ldw;
     g.ldy = 256; g.y_ns = (long)M * 256; g.M = M; g.N = 256; g.K = K; g.g[0].in = X; g.g[0].P = P; g.g[0].Y = Y;
     const dim3 grid(16 * 4 * nets);
-    double us = graph_us(s, [&] { hipLaunchKernelGGL(k_nt64, grid, dim3(512), 0, s, g); }, 20, 50);
+    double us = graph_us(s, [&] { hipLaunchKernelGGL((k_nt64<4, 2, 2>), grid, dim3(512), 0, s, g); }, 20, 50);
     char nm[64]; snprintf(nm, 64, "k_nt64 K=%d", K); show(nm, us, 3);
   }
   return 0;
