@@ -298,7 +298,9 @@ def main():
             out["replay_gather_hbm"] = {"record": "Humanoid-v4 (o=376, a=17), 1M-row ring", "rows_per_launch": 65536, "us": us_h,
                                         "algo_bytes": by_h, "achieved": by_h / us_h * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": by_h / us_h * 1e-3 / HBM_PEAK_GBS,
-                                        "traffic": "410 MB per launch from FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_gather_humanoid_b65536_pmc.csv) = 1.01x algorithmic"}
+                                        "traffic": 409.8e6, "traffic_unit": "bytes per launch",
+                                        "traffic_note": "PMC: FETCH_SIZE 103 539 KB x2 (gfx950 correction) + WRITE_SIZE 202 715 KB, separate --pmc passes, "
+                                                        "profiles/r01_gather_humanoid_b65536_pmc.csv = 1.01x the algorithmic bytes"}
             eh.close()
             # the op sizes are tiny: torch's default of one thread per host core (128 here) is slower than a few threads,
             # so time 1 and 8 threads on a bounded sample each and report the faster one
