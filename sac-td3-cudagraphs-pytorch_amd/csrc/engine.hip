@@ -860,18 +860,19 @@ int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const
       const int r = done_rows + i;
       pack_record(e, st + (size_t)i * e->rec_f, obs + (size_t)r * e->o, act + (size_t)r * e->a, rew[r], nobs + (size_t)r * e->o, dones[r]);
     }
-    int left = chunk, off = 0;
-    while (left > 0) {   // round-robin writes, wrapping at capacity
-      const int run = (int)std::min<int64_t>(left, cap - e->rb_cursor);
-      HIPCHK(hipMemcpyAsync(e->ring + (size_t)e->rb_cursor * e->rec_f, st + (size_t)off * e->rec_f,
-                            sizeof(float) * (size_t)run * e->rec_f, hipMemcpyHostToDevice, e->stream));
-      e->rb_cursor = (e->rb_cursor + run) % cap;
-      e->rb_len = std::min<int64_t>(cap, e->rb_len + run);
-      left -= run; off += run;
-    }
+    // one launch: the kernel reads the staged rows from pinned host memory, writes them round-robin into the ring
+    // (wrapping at capacity) and publishes the new length / cursor
+    IngestArgs g{};
+    g.src = (const float4*)st; g.ring = (float4*)e->ring; g.rec4 = e->rec4; g.n = chunk; g.cursor = (int)e->rb_cursor; g.cap = (int)cap;
+    e->rb_cursor = (e->rb_cursor + chunk) % cap;
+    e->rb_len = std::min<int64_t>(cap, e->rb_len + chunk);
+    g.len_cursor = &e->ctl->rb_len; g.new_len = (int)e->rb_len; g.new_cursor = (int)e->rb_cursor;
+    const int blocks = (int)std::min<long>(256, ((long)chunk * e->rec4 + 255) / 256);
+    hipLaunchKernelGGL(k_rb_ingest, dim3(std::max(blocks, 1)), dim3(256), 0, e->stream, g);
+    HIPCHK(hipGetLastError());
     done_rows += chunk;
   }
-  return n > 0 ? publish_rb_state(e) : 0;
+  return 0;
 }
 
 int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EINVAL; }

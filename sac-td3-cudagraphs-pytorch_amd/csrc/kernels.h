@@ -286,6 +286,21 @@ __global__ void k_set_int2(int* dst, int v0, int v1) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { dst[0] = v0; dst[1] = v1; }
 }
 
+// rb.extend (orchestrator.py:100-113): rows packed by the host into a pinned staging slot are copied into the ring by the
+// kernel itself (round-robin from `cursor`, wrapping at `cap`) and the new length / cursor are published with them --
+// one launch per call instead of a copy command plus a kernel.
+struct IngestArgs { const float4* src; float4* ring; int rec4, n, cursor, cap; int* len_cursor; int new_len, new_cursor; };
+__global__ __launch_bounds__(256) void k_rb_ingest(IngestArgs p) {
+  const int total = p.n * p.rec4;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+    const int row = g / p.rec4, c = g - row * p.rec4;
+    int dst = p.cursor + row;
+    if (dst >= p.cap) dst -= p.cap;
+    p.ring[(long)dst * p.rec4 + c] = p.src[g];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { p.len_cursor[0] = p.new_len; p.len_cursor[1] = p.new_cursor; }
+}
+
 struct FillArgs { float4* ring; int rec4, cx, cn, o, a; long n; unsigned long long seed; const float* min_ac; const float* max_ac; };
 __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
   const long g = (long)blockIdx.x * 256 + threadIdx.x;
