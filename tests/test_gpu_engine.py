@@ -131,6 +131,22 @@ def test_native_index_stream_matches_philox_oracle():
         assert np.array_equal(got["next_observations"], nobs[want_idx])
 
 
+def test_gather_with_several_chunks_per_thread():
+    """Above 2^20 16-byte chunks per batch k_gather gives every thread GATHER_CPT chunks of a contiguous span (the shape of the
+    bandwidth sweep): B = 4096 rows of a 600-wide observation = 1.2 M chunks.  Bit-exact against the host copy of the rows."""
+    o, a, B, seed = 600, 4, 4096, 99
+    eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=8192, seed=seed), [-1] * a, [1] * a)
+    obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(6000, o, a, 1.0, seed=8)]
+    eng.rb_extend(obs, act, rew, nobs, done)
+    for draw in range(2):
+        eng.rb_sample()
+        got = eng.read_batch()
+        idx = replay_ref.sample_indices(seed, draw, B, 6000)
+        assert np.array_equal(got["index"], idx)
+        assert np.array_equal(got["observations"], obs[idx]) and np.array_equal(got["next_observations"], nobs[idx])
+        assert np.array_equal(got["actions"], act[idx]) and np.array_equal(got["rewards"], rew[idx]) and np.array_equal(got["dones"], done[idx])
+
+
 def test_full_size_ring_properties():
     """BASELINE config 4 at full size (Humanoid-v4 records, 1 000 000 rows = 3.1 GB of HBM, B = 1024), where the ring cannot
     be mirrored on the host: size-independent properties instead.  (i) the native index stream is the Philox oracle's,
