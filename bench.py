@@ -58,6 +58,7 @@ def oracle_rate(w, device, seconds, threads=None, min_iters=0):
     hps = (Hps.td3 if w["td3"] else Hps.sac)(batch_size=B)
     torch.manual_seed(0)
     ag = RefAgent(o, a, [-w["bound"]] * a, [w["bound"]] * a, hps, device=device)
+    ag.keep_trace = False                     # the parity tests' bookkeeping (gradient clones) is not part of the step
     n = min(w["rows"], 100_000)
     g = torch.Generator().manual_seed(0)
     data = [torch.randn(n, o, generator=g), (torch.rand(n, a, generator=g) * 2 - 1) * w["bound"], torch.randn(n, generator=g),
@@ -82,6 +83,69 @@ def oracle_rate(w, device, seconds, threads=None, min_iters=0):
             if time.perf_counter() - t0 >= seconds and i >= min_iters:
                 break
     sync()
+    return i / (time.perf_counter() - t0), i
+
+
+def oracle_graph_rate(w, seconds):
+    """BASELINE.md baseline (iii): the same restatement on cuda:0 with update_qnets / update_actor captured as
+    torch.cuda.CUDAGraph and replayed -- the closest stand-in for the reference's CudaGraphModule mode (orchestrator.py:
+    313-315; sampling and the target update stay eager between the two graphs, as there).  Returns (iterations/s, n)."""
+    import torch
+    from oracle.sac_td3_ref import Hps, RefAgent
+    o, a, B = w["o"], w["a"], w["batch"]
+    hps = (Hps.td3 if w["td3"] else Hps.sac)(batch_size=B)
+    torch.manual_seed(0)
+    ag = RefAgent(o, a, [-w["bound"]] * a, [w["bound"]] * a, hps, device="cuda")
+    ag.keep_trace = False
+    for opt in (ag.q_optimizer, ag.actor_optimizer, getattr(ag, "alpha_optimizer", None)):
+        if opt is not None:
+            for grp in opt.param_groups:
+                grp["capturable"] = True
+    n = min(w["rows"], 100_000)
+    g = torch.Generator().manual_seed(0)
+    data = [torch.randn(n, o, generator=g), (torch.rand(n, a, generator=g) * 2 - 1) * w["bound"], torch.randn(n, generator=g),
+            torch.randn(n, o, generator=g), torch.rand(n, generator=g) < 0.01]
+    data = [d.cuda() for d in data]
+    static = ag.to_batch(*[d[:B].clone() for d in data])       # the graphs read these tensors; each sample is copied into them
+
+    def load():
+        idx = torch.randint(0, n, (B,), device="cuda")
+        for dst, src in zip((static.observations, static.actions, static.rewards, static.next_observations, static.dones), data):
+            dst.copy_(src[idx].to(dst.dtype))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                               # warm-up outside capture (allocations, Adam state)
+        for _ in range(3):
+            load(); ag.update_qnets(static); ag.update_actor(static); ag.update_targ_nets()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gq, ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gq):
+        ag.update_qnets(static)
+    with torch.cuda.graph(ga):
+        ag.update_actor(static)
+
+    def one(i):
+        load()
+        gq.replay()
+        ag.qnet_updates_so_far += 1
+        if i % (hps.actor_update_delay + 1) == 0:
+            for _ in range(hps.actor_update_delay):
+                ga.replay()
+        ag.update_targ_nets()
+
+    for i in range(6):
+        one(i)
+    torch.cuda.synchronize()
+    t0, i = time.perf_counter(), 0
+    while True:
+        one(i)
+        i += 1
+        if i % 3 == 0:
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= seconds:
+                break
     return i / (time.perf_counter() - t0), i
 
 
@@ -317,6 +381,14 @@ def main():
             out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
                                           "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
             out["speedup_vs_eager_rocm"] = out["value"] / v
+            try:
+                vg, ng = oracle_graph_rate(w, 4.0)
+                out["torch_cudagraph_rocm_baseline"] = {"value": vg, "unit": "gradient-steps/s",
+                                                        "sample": f"{ng} iterations, same restatement, update_qnets / update_actor as "
+                                                                  "torch.cuda.CUDAGraph replays (the reference's cudagraphs: true mode), sampling and target update eager"}
+                out["speedup_vs_torch_cudagraph_rocm"] = out["value"] / vg
+            except Exception as ex:   # capture support for an op can differ between torch / ROCm versions: report, do not fail the run
+                out["torch_cudagraph_rocm_baseline"] = {"value": None, "error": repr(ex)[:300]}
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -235,6 +235,7 @@ class RefAgent:
                 self.targ_ent = -ac_dim
                 self.alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=hps.log_alpha_lr)
         self.trace: Dict[str, torch.Tensor] = {}  # intermediates of the last update, for parity tests
+        self.keep_trace = True  # False when timed as a baseline: the gradient clones below are not part of the reference's step
 
     # -- helpers
     @property
@@ -281,9 +282,10 @@ class RefAgent:
         q = self._twin(self.qnets, b.observations, b.actions)
         loss = sum(torch.nn.functional.mse_loss(q[i].view(-1), targ_q) for i in range(2))
         loss.backward()
-        self.trace.update(next_action=a_next, next_logp=logp_next, q_target=q_t.squeeze(-1), targ_q=targ_q,
-                          q=q.detach().squeeze(-1),
-                          q_grads=[p.grad.clone() for p in self.qnets.parameters()])
+        if self.keep_trace:
+            self.trace.update(next_action=a_next, next_logp=logp_next, q_target=q_t.squeeze(-1), targ_q=targ_q,
+                              q=q.detach().squeeze(-1),
+                              q_grads=[p.grad.clone() for p in self.qnets.parameters()])
         self.q_optimizer.step()
         return {"loss/qf_loss": loss.detach()}
 
@@ -307,10 +309,11 @@ class RefAgent:
         actor_loss.backward()
         if h.clip_norm > 0:
             nn.utils.clip_grad_norm_(self.actor.parameters(), h.clip_norm)
-        self.trace.update(pi_action=a_pi.detach(), q_pi=q_pi.detach().squeeze(-1),
-                          actor_grads=[p.grad.clone() for p in self.actor.parameters()])
-        if not h.prefer_td3_over_sac:
-            self.trace["pi_logp"] = logp.detach()
+        if self.keep_trace:
+            self.trace.update(pi_action=a_pi.detach(), q_pi=q_pi.detach().squeeze(-1),
+                              actor_grads=[p.grad.clone() for p in self.actor.parameters()])
+            if not h.prefer_td3_over_sac:
+                self.trace["pi_logp"] = logp.detach()
         self.actor_optimizer.step()
         out = {"loss/actor_loss": actor_loss.detach()}
         if h.prefer_td3_over_sac:
@@ -321,7 +324,8 @@ class RefAgent:
                 _, logp2, _ = self.actor.get_action(b.observations, eps_alpha).values()
             alpha_loss = (self.alpha * (-logp2 - self.targ_ent).detach()).mean()
             alpha_loss.backward()
-            self.trace["alpha_logp"] = logp2
+            if self.keep_trace:
+                self.trace["alpha_logp"] = logp2
             self.alpha_optimizer.step()
             out["loss/alpha_loss"] = alpha_loss.detach()
         out["vitals/alpha"] = self.alpha.detach()
