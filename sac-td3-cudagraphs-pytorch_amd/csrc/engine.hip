@@ -1018,8 +1018,15 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
   }
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
   ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr);
-  if (explore) t.tick = &e->ctl->predict_ctr;
+  // the tail reads predict_ctr (its noise stream) and may only advance it itself when it is a single block: with more
+  // rows than one block holds, a late block could read the counter after block 0 has bumped it
+  const bool one_block = n <= 16;
+  if (explore && one_block) t.tick = &e->ctl->predict_ctr;
   RCCHK(launch_tail(e, e->stream, t));
+  if (explore && !one_block) {
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int i = 0; i < n; ++i) memcpy(actions + (size_t)i * e->a, e->h_act + (size_t)i * e->a4, sizeof(float) * e->a);
   return 0;

@@ -433,6 +433,28 @@ def test_predict(algo, env):
         eng.predict(torch.zeros(9, o), explore=False)
 
 
+def test_predict_many_envs_is_reproducible():
+    """predict for more rows than one 16-row block (a large vector env): exploitation matches the oracle and the native
+    exploration stream is a function of (seed, call number, row) only -- two engines with the same seed agree call by
+    call, whichever block of the kernel a row lands in."""
+    o, a, bound = DIMS["hopper"]
+    hps = Hps.sac(batch_size=32)
+    torch.manual_seed(0)
+    ref = RefAgent(o, a, [-bound] * a, [bound] * a, hps)
+    engs = [P.Engine(P.Config.from_hps(hps, o, a, rb_capacity=256, max_envs=48, seed=7), [-bound] * a, [bound] * a) for _ in range(2)]
+    for e in engs:
+        push_params(e, ref)
+    obs = torch.randn(40, o, generator=torch.Generator().manual_seed(3))
+    close(engs[0].predict(obs, explore=False), ref.predict(obs, explore=False), name="exploit, 40 rows")
+    seq = [[e.predict(obs, explore=True) for _ in range(3)] for e in engs]
+    for x, y in zip(*seq):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(seq[0][0], seq[0][1]) and not np.array_equal(seq[0][1], seq[0][2])
+    eps = torch.randn(40, a, generator=torch.Generator().manual_seed(4))
+    engs[0].set_noise(_lib.SITE_PREDICT, eps)
+    close(engs[0].predict(obs, explore=True), ref.predict(obs, explore=True, eps=eps), name="explore (injected), 40 rows")
+
+
 def test_agent_mirror_drives_like_the_reference():
     """The Python `Agent`/`ReplayBuffer` mirror, used the way orchestrator.py:317-352 uses the reference's."""
     from types import SimpleNamespace
