@@ -86,6 +86,7 @@ struct sactd3_engine {
   int o = 0, a = 0, B = 0, ldc = 0, ldo = 0, a4 = 0, nh = 0, ldu = 0, rec_f = 0, rec4 = 0, cx = 0, cn = 0;
   int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
   int nblk = 0, nblk4 = 0;     // row-kernel blocks for B rows: 16 rows each (MFMA-using tails) / 4 rows each (plain row kernels)
+  AlphaArgs pending_alpha{}; bool alpha_pending = false;   // a temperature step deferred into the next update's trunk launch (enqueue time only)
   int maxn = 0;                // rows accepted by predict
   int num_cus = 256;
   int stage_rows = 0;
@@ -196,7 +197,7 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     const int rb = 64 / ks;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * tiles_n;
-    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks), 1, (unsigned)nets);
+    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0)), 1, (unsigned)nets);
     if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, gg); else launch_nt_f1<2>(s, ks, grid, gg); }
     else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, gg); else launch_nt_ks<2, false, 0>(s, ks, grid, gg); }
   }
@@ -232,7 +233,8 @@ static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] 
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
 struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
-struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false; };
+struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false;
+                    const AlphaArgs* alpha = nullptr; };   // alpha: a pending temperature step to carry as one extra block
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
@@ -243,8 +245,13 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.g[i].P = grp[i].P; h.g[i].Y = grp[i].z2; h.g[i].xh_out = grp[i].xh; h.g[i].h_out = grp[i].h; h.g[i].rstd_out = grp[i].rstd;
   }
   const int nets = ngrp * npg;
+  const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4;
+  if (tk.alpha && (big_path || K > 64)) {   // only the fused-first-layer launch can carry it: otherwise its own node, first
+    hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, *tk.alpha);
+    HIPCHK(hipGetLastError());
+  }
   // MFMA-bound sizes with enough 64 x 64 tiles to fill the chip: tiled GEMM -> LayerNorm row kernel -> tiled GEMM
-  if (M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4) {
+  if (big_path) {
     NtArgs g{};
     g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
     g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
@@ -275,6 +282,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.ld_in = ldx; h.in_ns = 0; h.K1 = K; h.oW1 = L.W1; h.ldw1 = L.ld1; h.oB1 = L.b1;
     h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.adam_pw = tk.adam_pw; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
     h.w1_magic = magic_div((unsigned)L.ld1, 4u * HID * (unsigned)L.ld1);
+    if (tk.alpha) { h.alpha_block = 1; h.al = *tk.alpha; }
     if (tk.fuse_gather) {   // x = the s' field of the sampled records; extra blocks fill the batch slot (see NtArgs)
       h.ring_rows = 1; h.ring_off = e->ldc; h.ga = gather_args(e, e->ring, -1);
       h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
@@ -422,7 +430,9 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   }
   {  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
     const TrunkGrp g{e->Xp, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
+    TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+    if (e->alpha_pending) { tk.alpha = &e->pending_alpha; e->alpha_pending = false; }   // the previous update's temperature step
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, tk));
   }
   {
     ActorQTail t{};
@@ -515,8 +525,11 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     AlphaArgs al{};
     al.logp = e->logp_al; al.B = B; al.targ_ent = -(float)e->a; al.autotune = c.autotune; al.la = e->la; al.ctl = e->ctl;
     al.lr = c.log_alpha_lr; al.b1 = c.adam_beta1; al.b2 = c.adam_beta2; al.eps = c.adam_eps; al.tick = &e->ctl->noise_ctr;
-    hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, al);
-    HIPCHK(hipGetLastError());
+    if (merge_next) { e->pending_alpha = al; e->alpha_pending = true; }   // rides in the next update's critic-trunk launch
+    else {
+      hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, al);
+      HIPCHK(hipGetLastError());
+    }
   }
   return 0;
 }

@@ -342,6 +342,49 @@ __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).z, (b).z, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).w, (b).w, acc, 0, 0, 0);
 
+struct AlphaArgs {
+  const float* logp; int B; float targ_ent; int autotune;
+  float* la;                             // [0] log_alpha, [1] exp_avg, [2] exp_avg_sq
+  DevCtl* ctl; float lr, b1, b2, eps;
+  int* tick;
+};
+// (a device function: also runs as one extra block of the next update's critic-trunk launch, see NtArgs::al)
+__device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
+  __shared__ float red[4];
+  // the lead thread's state is requested together with the log-probs: fetched one after the other behind the
+  // reduction it would be four dependent round trips in a kernel that does nothing else
+  const bool lead = threadIdx.x == 0;
+  float la = 0.f, m = 0.f, v = 0.f; int tl = 0, tk = 0; double q0 = 0.0, q1 = 0.0;
+  if (lead) {
+    la = a.la[0];
+    if (a.autotune) { m = a.la[1]; v = a.la[2]; tl = a.ctl->t_l; q0 = a.ctl->pw_l[0]; q1 = a.ctl->pw_l[1]; }
+    if (a.tick) tk = *a.tick;
+  }
+  float s = 0.f;
+  if (a.autotune)
+    for (int i = threadIdx.x; i < a.B; i += 256) s += -a.logp[i] - a.targ_ent;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (lead) {
+    if (a.autotune) {
+      const float mean_term = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
+      const float g = expf(la) * mean_term;          // d/dlog_alpha of alpha * mean_term; also the loss value
+      a.ctl->metrics[2] = g;
+      const double p1 = q0 * (double)a.b1, p2 = q1 * (double)a.b2;      // adam_tick on (t_l, pw_l)
+      a.ctl->t_l = tl + 1; a.ctl->pw_l[0] = p1; a.ctl->pw_l[1] = p2;
+      const float sc0 = (float)((double)a.lr / (1.0 - p1)), sc1 = (float)sqrt(1.0 - p2);
+      m = m + (g - m) * (1.0f - a.b1);
+      v = v * a.b2 + g * g * (1.0f - a.b2);
+      la -= sc0 * (m / (sqrtf(v) / sc1 + a.eps));
+      a.la[0] = la; a.la[1] = m; a.la[2] = v;
+    }
+    a.ctl->metrics[3] = expf(la);
+    if (a.tick) *a.tick = tk + 1;
+  }
+}
+__global__ __launch_bounds__(256) void k_alpha_step(AlphaArgs a) { alpha_body(a); }
+
 struct NtGrp {               // one group of nets sharing an input and a parameter arena
   const float* in;                          // input rows: A (plain) or x (FUSE1); net stride in_ns
   const float* P;                           // parameter arena of the group's first net; net stride p_ns
@@ -363,6 +406,9 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // ring (row = this sample's index, field offset ring_off floats) and `gblocks` extra blocks at the end of the grid do
   // the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.
   int ring_rows; int ring_off; int nt_blocks; int gblocks; GatherArgs ga;
+  // One more block (after the gather blocks, net 0 only) can carry the temperature step of the PREVIOUS actor update
+  // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
+  int alpha_block; AlphaArgs al;
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -393,8 +439,9 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
-  if (FUSE1 && p.gblocks && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: these blocks are the replay gather
-    gather_body(p.ga, blockIdx.x - p.nt_blocks);
+  if (FUSE1 && (p.gblocks || p.alpha_block) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step
+    if ((int)blockIdx.x < p.nt_blocks + p.gblocks) gather_body(p.ga, blockIdx.x - p.nt_blocks);
+    else if (blockIdx.z == 0) alpha_body(p.al);
     return;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
@@ -1571,47 +1618,6 @@ __global__ __launch_bounds__(256) void k_polyak(PolyakArgs a) {
     const float* p = i < a.n0 ? a.p0 + i : a.p1 + (i - a.n0);
     const float4 tt = ld4(t);
     st4(t, tt + (ld4(p) - tt) * a.tau);
-  }
-}
-
-struct AlphaArgs {
-  const float* logp; int B; float targ_ent; int autotune;
-  float* la;                             // [0] log_alpha, [1] exp_avg, [2] exp_avg_sq
-  DevCtl* ctl; float lr, b1, b2, eps;
-  int* tick;
-};
-__global__ __launch_bounds__(256) void k_alpha_step(AlphaArgs a) {
-  __shared__ float red[4];
-  // the lead thread's state is requested together with the log-probs: fetched one after the other behind the
-  // reduction it would be four dependent round trips in a kernel that does nothing else
-  const bool lead = threadIdx.x == 0;
-  float la = 0.f, m = 0.f, v = 0.f; int tl = 0, tk = 0; double q0 = 0.0, q1 = 0.0;
-  if (lead) {
-    la = a.la[0];
-    if (a.autotune) { m = a.la[1]; v = a.la[2]; tl = a.ctl->t_l; q0 = a.ctl->pw_l[0]; q1 = a.ctl->pw_l[1]; }
-    if (a.tick) tk = *a.tick;
-  }
-  float s = 0.f;
-  if (a.autotune)
-    for (int i = threadIdx.x; i < a.B; i += 256) s += -a.logp[i] - a.targ_ent;
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (lead) {
-    if (a.autotune) {
-      const float mean_term = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
-      const float g = expf(la) * mean_term;          // d/dlog_alpha of alpha * mean_term; also the loss value
-      a.ctl->metrics[2] = g;
-      const double p1 = q0 * (double)a.b1, p2 = q1 * (double)a.b2;      // adam_tick on (t_l, pw_l)
-      a.ctl->t_l = tl + 1; a.ctl->pw_l[0] = p1; a.ctl->pw_l[1] = p2;
-      const float sc0 = (float)((double)a.lr / (1.0 - p1)), sc1 = (float)sqrt(1.0 - p2);
-      m = m + (g - m) * (1.0f - a.b1);
-      v = v * a.b2 + g * g * (1.0f - a.b2);
-      la -= sc0 * (m / (sqrtf(v) / sc1 + a.eps));
-      a.la[0] = la; a.la[1] = m; a.la[2] = v;
-    }
-    a.ctl->metrics[3] = expf(la);
-    if (a.tick) *a.tick = tk + 1;
   }
 }
 
