@@ -178,8 +178,14 @@ static void launch_nt_ks(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
   else hipLaunchKernelGGL((k_nt<PRO, F1, 1, C1>), grid, dim3(256), 0, s, g);
 }
 template <int PRO>
-static void launch_nt_f1(hipStream_t s, int ks, dim3 grid, const NtArgs& g) {
+static void launch_nt_f1(hipStream_t s, int ks, int nt, dim3 grid, const NtArgs& g) {
   const int c1 = (g.K1 + 15) / 16;
+  if (nt == 2) {   // (KS == 2 only) two column tiles per block
+    if (c1 <= 1) hipLaunchKernelGGL((k_nt<PRO, true, 2, 1, 2>), grid, dim3(256), 0, s, g);
+    else if (c1 == 2) hipLaunchKernelGGL((k_nt<PRO, true, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_nt<PRO, true, 2, 4, 2>), grid, dim3(256), 0, s, g);
+    return;
+  }
   if (c1 <= 1) launch_nt_ks<PRO, true, 1>(s, ks, grid, g);
   else if (c1 == 2) launch_nt_ks<PRO, true, 2>(s, ks, grid, g);
   else launch_nt_ks<PRO, true, 4>(s, ks, grid, g);
@@ -195,10 +201,14 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
     if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) ks = v; }   // tuning aid
     const int rb = 64 / ks;
+    // two column tiles per block when the launch would otherwise put two rounds of blocks on every CU: the fused first
+    // layer is then recomputed by half as many blocks
+    int nt = (fuse1 && ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
+    if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) nt = 1; }   // tuning aid
     NtArgs gg = g;
-    gg.nt_blocks = ((g.M + rb - 1) / rb) * tiles_n;
+    gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0)), 1, (unsigned)nets);
-    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, grid, gg); else launch_nt_f1<2>(s, ks, grid, gg); }
+    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, nt, grid, gg); else launch_nt_f1<2>(s, ks, nt, grid, gg); }
     else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, gg); else launch_nt_ks<2, false, 0>(s, ks, grid, gg); }
   }
   HIPCHK(hipGetLastError());

@@ -430,15 +430,17 @@ __device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 
 // The host picks KS so that a launch has about one block per CU: what a CU can fetch per clock (~13 B coalesced,
 // ~7 B in 64-byte pieces) bounds these kernels, so W tiles (and the whole of W1) are fetched ONCE per block with
 // fully coalesced loads, parked in LDS and shared by the block's waves.
-template <int PRO, bool FUSE1, int KS, int C1>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
+// NT = 16-column tiles per block: 2 halves the number of blocks that recompute the fused first layer (4-net launches, where
+// NT = 1 means two rounds of blocks per CU)
+template <int PRO, bool FUSE1, int KS, int C1, int NT = 1>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   constexpr int RB = 64 / KS, CW = 16 / KS, NP = 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
   constexpr int W1S = 16 * (C1 > 0 ? C1 : 1) + 4;                           // LDS row stride of W1 (K1 <= 16 C1)
-  __shared__ __attribute__((aligned(16))) float W2s[16 * AS];
+  __shared__ __attribute__((aligned(16))) float W2s[NT * 16 * AS];
   __shared__ __attribute__((aligned(16))) float W1s[FUSE1 ? HID * W1S : 4];
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
-  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 4 * 64 * 4 : 4];
+  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
   if (FUSE1 && (p.gblocks || p.alpha_block) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step
     if ((int)blockIdx.x < p.nt_blocks + p.gblocks) gather_body(p.ga, blockIdx.x - p.nt_blocks);
     else if (blockIdx.z == 0) alpha_body(p.al);
@@ -453,17 +455,18 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
   const float* Pn = G.P + ni * p.p_ns;
-  const int tiles_n = (p.N + 15) >> 4;
+  const int tiles_n = (p.N + 16 * NT - 1) / (16 * NT);
   const int tmb = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-  const int m0 = tmb * RB + 16 * mt, n0 = tn * 16;          // this wave's rows / the block's columns
+  const int m0 = tmb * RB + 16 * mt, n0 = tn * 16 * NT;          // this wave's rows / the block's columns
   const int mrow = min(m0 + r, p.M - 1);
   const int kb = (ks * CW) * 16 + 4 * kq;                    // first k of this lane's fragments
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   // requested here, used by the epilogue: a load issued among the epilogue's stores makes each store wait for the last
-  const float bias = p.oBias >= 0 ? Pn[p.oBias + min(n0 + r, p.N - 1)] : 0.f;
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 16 * nt + r, p.N - 1)] : 0.f;
   STAMP(0);
   // ---- 1. every global load, coalesced where the data is shared by the block
-  float4 w2r[4], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
+  float4 w2r[4 * NT], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
   const int w1n = FUSE1 ? (HID * p.ldw1) >> 2 : 0;           // float4s of W1 (rows are 16-byte multiples, contiguous)
   if (FUSE1) {
 #pragma unroll
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   // the second layer's W tile is requested LAST (loads return in order): the first layer and the row statistics run
   // while it is still in flight
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {                              // 16 rows x 256 floats, one row per wave-instruction
+  for (int u = 0; u < 4 * NT; ++u) {                         // 16 NT rows x 256 floats, one row per wave-instruction
     const int i = t + 256 * u, row = i >> 6, c4 = i & 63, n = min(n0 + row, p.N - 1);
     w2r[u] = ld4(Pn + p.oW + (long)n * p.ldw + 4 * c4);
   }
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     }
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { const int i = t + 256 * u; st4(W2s + (i >> 6) * AS + 4 * (i & 63), w2r[u]); }
+  for (int u = 0; u < 4 * NT; ++u) { const int i = t + 256 * u; st4(W2s + (i >> 6) * AS + 4 * (i & 63), w2r[u]); }
   // ---- 3. prologue on the A rows held in registers
   float4 xh[CW];
   float rstd = 1.f;
@@ -588,36 +591,47 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     }
     if (G.rstd_out && ks == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
   }
-  // ---- 4. second layer: this wave's rows x the block's 16 columns over its K range (W tile from LDS)
-  const float* wrow = W2s + r * AS + kb;
+  // ---- 4. second layer: this wave's rows x the block's 16 NT columns over its K range (W tiles from LDS)
+  f32x4 acc[NT];
 #pragma unroll
-  for (int c = 0; c < CW; c += 2) {
-    const float4 w0 = ld4(wrow + 16 * c);
-    MFMA4(acc0, av[c], w0);
-    if (c + 1 < CW) { const float4 w1 = ld4(wrow + 16 * c + 16); MFMA4(acc1, av[c + 1], w1); }
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const float* wrow = W2s + (16 * nt + r) * AS + kb;
+#pragma unroll
+    for (int c = 0; c < CW; c += 2) {
+      const float4 w0 = ld4(wrow + 16 * c);
+      MFMA4(a0, av[c], w0);
+      if (c + 1 < CW) { const float4 w1 = ld4(wrow + 16 * c + 16); MFMA4(a1, av[c + 1], w1); }
+    }
+    acc[nt][0] = a0[0] + a1[0]; acc[nt][1] = a0[1] + a1[1]; acc[nt][2] = a0[2] + a1[2]; acc[nt][3] = a0[3] + a1[3];
   }
-  f32x4 acc;
-  acc[0] = acc0[0] + acc1[0]; acc[1] = acc0[1] + acc1[1]; acc[2] = acc0[2] + acc1[2]; acc[3] = acc0[3] + acc1[3];
   STAMP(3);
   if (KS > 1) {                               // sum the KS K-slices of each 16 x 16 tile; the ks == 0 wave keeps the total
-    st4(red + (wave * 64 + lane) * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
     __syncthreads();
     if (ks == 0) {
 #pragma unroll
-      for (int j = 1; j < KS; ++j) {
-        const float4 o = ld4(red + ((wave + j) * 64 + lane) * 4);
-        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 1; j < KS; ++j) {
+          const float4 o = ld4(red + ((nt * 4 + wave + j) * 64 + lane) * 4);
+          acc[nt][0] += o.x; acc[nt][1] += o.y; acc[nt][2] += o.z; acc[nt][3] += o.w;
+        }
     }
   }
   STAMP(4);
-  const int col = n0 + (lane & 15);
-  if (ks == 0 && col < p.N) {
+  if (ks == 0) {
     float* y = G.Y + ni * p.y_ns;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = m0 + 4 * (lane >> 4) + i;
-      if (row < p.M) y[(long)row * p.ldy + col] = acc[i] + bias;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + 16 * nt + (lane & 15);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * (lane >> 4) + i;
+        if (row < p.M) y[(long)row * p.ldy + col] = acc[nt][i] + bias[nt];
+      }
     }
   }
   STAMP(5);
