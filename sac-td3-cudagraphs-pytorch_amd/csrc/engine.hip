@@ -221,12 +221,21 @@ static int launch_nn(sactd3_engine* e, hipStream_t s, const NnArgs& g, int nets)
   return 0;
 }
 static int launch_tn(sactd3_engine* e, hipStream_t s, TnArgs& g, int nets) {
-  int tiles = 0;
-  for (int i = 0; i < g.nprob; ++i) {
-    g.pr[i].tile0 = tiles;
-    tiles += ((g.pr[i].N + 15) / 16) * ((g.pr[i].ldw + 15) / 16);
-  }
-  hipLaunchKernelGGL(k_tn, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
+  auto count = [&](int kt) {
+    int tiles = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+      g.pr[i].tile0 = tiles;
+      tiles += ((g.pr[i].N + 15) / 16) * (((g.pr[i].ldw + 15) / 16 + kt - 1) / kt);
+    }
+    return tiles;
+  };
+  // two k tiles per block (one dY slice fetched and transposed for both) once single tiles would be more than two blocks per CU
+  // (the critics' launch at B = 256: 544 blocks -> 288, -0.6 us per iteration)
+  int kt = (count(1) * nets > 2 * e->num_cus && g.M < BIG_BATCH) ? 2 : 1;   // (measured: no gain with a thousand rows per tile)
+  if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) kt = v; }   // tuning aid
+  const int tiles = count(kt);
+  if (kt == 2) hipLaunchKernelGGL(k_tn<2>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(k_tn<1>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }

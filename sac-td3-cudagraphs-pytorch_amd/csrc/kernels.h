@@ -900,10 +900,13 @@ __device__ __forceinline__ void adam_commit(const TnArgs& p, long off, float g, 
   }
 }
 
+// KT = 16-column k tiles per block (1 or 2): with 2 the dY slice is fetched and transposed once for two weight tiles, wave 0
+// and wave 1 commit one each -- used when a launch would otherwise put more than two blocks on every CU.
+template <int KT>
 __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float red[KT * 4 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
-  __shared__ __attribute__((aligned(16))) float Xs[256 * YS];
+  __shared__ __attribute__((aligned(16))) float Xs[KT * 256 * YS];
   __shared__ float cred[4 * 16 * 17];                    // [entry: 3 finalised vectors + the bias][16 partial groups][16 columns]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
@@ -912,12 +915,12 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
   const TnProb& q = p.pr[pi];    // stays in the kernarg segment (a private copy indexed at run time would be scratch memory)
   const int local = blockIdx.x - q.tile0;
-  const int tiles_k = (q.ldw + 15) >> 4;
+  const int tiles_k = (((q.ldw + 15) >> 4) + KT - 1) / KT;
   const int tn = local / tiles_k, tk = local % tiles_k;
-  const int n0 = tn * 16, k0 = tk * 16;
+  const int n0 = tn * 16, k0 = tk * 16 * KT;
   const long nbase = net * p.g_ns;
-  // the epilogue's elements: wave 0, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + j
-  const int ecol = k0 + (lane & 15);
+  // the epilogue's elements: wave kt < KT, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + 16 kt + j
+  const int ecol = k0 + 16 * min(wave, KT - 1) + (lane & 15);
   AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   // Requests go out in the order main operands -> optimiser state -> vector-gradient partials, so that the waits the
@@ -926,21 +929,24 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   const float* dYn = q.dY + net * q.dy_ns;
   const float* Xn = q.X + net * q.x_ns;
   const int Nr = (q.N + 3) & ~3, Kr = (q.K + 3) & ~3;     // rows hold at least round4(.) floats
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
-  float4 vy[4], vx[4];
+  float4 vy[4], vx[KT][4];
   auto fetch = [&](int mb) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
       const long mc = min(m, p.M - 1);
       vy[u] = ld4_cols(dYn + mc * q.ldy, n, q.N, Nr, m < p.M);
-      vx[u] = ld4_cols(Xn + mc * q.ldx, k, q.K, Kr, m < p.M);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) vx[kt][u] = ld4_cols(Xn + mc * q.ldx, k + 16 * kt, q.K, Kr, m < p.M);
     }
   };
   fetch(0);
   const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
-  if (wave == 0) {
+  if (wave < KT) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {          // clamped, not predicated (the commit is predicated)
       const int row = min(n0 + 4 * (lane >> 4) + i, q.N - 1);
@@ -994,17 +1000,21 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u;
       st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]);
-      st4(Xs + (i >> 2) * YS + 4 * (i & 3), vx[u]);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) st4(Xs + kt * 256 * YS + (i >> 2) * YS + 4 * (i & 3), vx[kt][u]);
     }
     if (mb + 256 < p.M) fetch(mb + 256);                   // the next slab's rows fly under this slab's MFMAs
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                          // wave w: 16-row chunks w, w+4, w+8, w+12 of this slab
       const float* y0 = Ys + (16 * (wave + 4 * u) + 4 * kq) * YS + r;
-      const float* x0 = Xs + (16 * (wave + 4 * u) + 4 * kq) * YS + r;
       const float4 a = make_float4(y0[0], y0[YS], y0[2 * YS], y0[3 * YS]);
-      const float4 b = make_float4(x0[0], x0[YS], x0[2 * YS], x0[3 * YS]);
-      MFMA4(acc, a, b);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const float* x0 = Xs + kt * 256 * YS + (16 * (wave + 4 * u) + 4 * kq) * YS + r;
+        const float4 b = make_float4(x0[0], x0[YS], x0[2 * YS], x0[3 * YS]);
+        MFMA4(acc[kt], a, b);
+      }
     }
     if (tk == 0 && q.b_off >= 0) {
       const int col = t & 15, part = t >> 4;
@@ -1013,13 +1023,19 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
   }
   STAMP(2);
-  acc = splitk_reduce(red, acc, wave, lane);
+  // sum the 4 waves' accumulators of every tile (split-M); wave kt gets the total of tile kt
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st4(red + ((kt * 4 + wave) * 64 + lane) * 4, make_float4(acc[kt][0], acc[kt][1], acc[kt][2], acc[kt][3]));
+  __syncthreads();
   STAMP(3);
-  if (wave == 0 && ecol < q.ldw) {
+  if (wave < KT && ecol < q.ldw) {
+    const float* rr = red + (wave * 4 * 64 + lane) * 4;
+    const float4 a = ld4(rr), b = ld4(rr + 256), c = ld4(rr + 512), d = ld4(rr + 768);
+    const float o[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = n0 + 4 * (lane >> 4) + i;
-      if (row < q.N) adam_commit(p, nbase + q.w_off + (long)row * q.ldw + ecol, ecol < q.K ? acc[i] : 0.f, st[i], step, sq2);
+      if (row < q.N) adam_commit(p, nbase + q.w_off + (long)row * q.ldw + ecol, ecol < q.K ? o[i] : 0.f, st[i], step, sq2);
     }
   }
   if (tk == 0) {

@@ -65,10 +65,10 @@ int main() {
     q1.nfin = 2; q1.fin_slot[0] = 3; q1.fin_off[0] = g1; q1.fin_slot[1] = 4; q1.fin_off[1] = be1; q1.fin_s_off = -1; q1.fin_nblk[0] = q1.fin_nblk[1] = 16; q1.tile0 = 256;
     g.pr[0] = q0; g.pr[1] = q1; g.apply = 1; g.P = P; g.Mo = Mo; g.Vo = Vo; g.T = T; g.tau = 0.005f; g.adam = adam; g.b1 = 0.9f; g.b2 = 0.999f; g.eps = 1e-8f;
     g.part = part; g.pstride = 16; g.part_s = ps; g.loss_part = ps; g.loss_n = 32; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.f / B; g.loss_dst = adam + 2;
-    double us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
+    double us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn<1>, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
     show("k_tn critics (+Adam)", us, 5);
     g.apply = 0;
-    us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
+    us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn<1>, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
     show("k_tn critics (grads only)", us, 5);
   }
   {
