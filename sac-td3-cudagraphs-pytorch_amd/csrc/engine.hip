@@ -202,14 +202,17 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
     if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) ks = v; }   // tuning aid
     const int rb = 64 / ks;
     // two column tiles per block when the launch would otherwise put two rounds of blocks on every CU: the fused first
-    // layer is then recomputed by half as many blocks
-    int nt = (fuse1 && ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
+    // layer is then recomputed (or the A rows fetched and normalised) by half as many blocks
+    int nt = (ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
     if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) nt = 1; }   // tuning aid
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0)), 1, (unsigned)nets);
     if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, nt, grid, gg); else launch_nt_f1<2>(s, ks, nt, grid, gg); }
-    else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, gg); else launch_nt_ks<2, false, 0>(s, ks, grid, gg); }
+    else if (nt == 2) {   // (KS == 2) the A rows are fetched and normalised by half as many blocks
+      if (pro == 1) hipLaunchKernelGGL((k_nt<1, false, 2, 0, 2>), grid, dim3(256), 0, s, gg);
+      else hipLaunchKernelGGL((k_nt<2, false, 2, 0, 2>), grid, dim3(256), 0, s, gg);
+    } else { if (pro == 1) launch_nt_ks<1, false, 0>(s, ks, grid, gg); else launch_nt_ks<2, false, 0>(s, ks, grid, gg); }
   }
   HIPCHK(hipGetLastError());
   return 0;
