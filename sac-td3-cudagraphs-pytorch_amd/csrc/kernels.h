@@ -1145,10 +1145,16 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   float e_in1 = 0.f, e_in2 = 0.f;
   if (need_eps) e_in1 = p.eps[ej];               // fetched whether or not it is an injected draw: branching on the
   if (p.dual) e_in2 = p.eps2[ej];                // (loaded) injection flag here would hold back every later request
-  float ob[4] = {0.f, 0.f, 0.f, 0.f};
+  // observation slice to copy (builds [s | pi(s)] rows): 16-byte chunks sub and sub + 16 of the row and the < 4 trailing
+  // floats (the chunk that straddles the action columns is NOT moved as a whole: another thread writes the action there)
+  const int o4 = p.o >> 2, orem = p.o & 3;
+  float4 ob4[2] = {f4(0.f), f4(0.f)};
+  float obt = 0.f;
   if (p.obs_src) {
+    const float* srow = p.obs_src + (long)bc * p.lds;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ob[i] = p.obs_src[(long)bc * p.lds + min(sub + 16 * i, p.o - 1)];
+    for (int i = 0; i < 2; ++i) ob4[i] = ld4(srow + 4 * min(sub + 16 * i, max(o4 - 1, 0)));
+    obt = srow[min(4 * o4 + sub, p.o - 1)];
   }
   // native draws (no memory involved)
   const float e_nat1 = need_eps ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
@@ -1170,7 +1176,8 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     }
   PIN(e_bh0); PIN(e_bh1); PIN(e_sc); PIN(e_bi); PIN(e_lo); PIN(e_hi); PIN(e_in1); PIN(e_in2); PIN(tick_v);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) PIN(ob[i]);
+  for (int i = 0; i < 2; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
+  PIN(obt);
   const float e_eps = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
   const float e_eps2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
   if (valid) {
@@ -1184,12 +1191,20 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       if (p.dual && !inj2) p.eps2[ej] = e_nat2;
     }
     if (p.obs_src) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (sub + 16 * i < p.o) p.dst[(long)b * p.ldd + sub + 16 * i] = ob[i];
       const float* __restrict__ src = p.obs_src + (long)b * p.lds;
       float* __restrict__ dst = p.dst + (long)b * p.ldd;
-      for (int k = sub + 64; k < p.o; k += 16) dst[k] = src[k];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (sub + 16 * i < o4) st4(dst + 4 * (sub + 16 * i), ob4[i]);
+      if (sub < orem) dst[4 * o4 + sub] = obt;
+      for (int c = sub + 32; c < o4; c += 64) {            // observations wider than 128: four chunks in flight per trip
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ld4(src + 4 * min(c + 16 * i, o4 - 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c + 16 * i < o4) st4(dst + 4 * (c + 16 * i), v[i]);
+      }
     }
   }
   __syncthreads();
