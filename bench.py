@@ -7,11 +7,20 @@ resident in HBM: replay index draw + gather, critic update, (every 3rd iteration
 same batch, Polyak.  Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hopper_sac|halfcheetah_td3|humanoid_sac]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` (N > 1) started WITHOUT a torch.distributed.run environment launches the N one-GPU ranks itself (the
+parent touches no GPU: it only starts `python -m torch.distributed.run --nproc-per-node N ... bench.py ...` as a child,
+the reference's counterpart being one OS process per seed, spawner.py:291,313-349); started by torch.distributed.run
+(RANK / WORLD_SIZE set) it is one of those ranks.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,7 +32,15 @@ WORKLOADS = {  # SURVEY.md section 8d / BASELINE.md section 3
     "halfcheetah_td3": dict(env="HalfCheetah-v4", o=17, a=6, bound=1.0, td3=True, batch=256, rows=100_000, capacity=1_000_000),
     "humanoid_sac": dict(env="Humanoid-v4", o=376, a=17, bound=0.4, td3=False, batch=1024, rows=1_000_000, capacity=1_000_000),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32), the type the path computes in
+DELAY = 2                 # actor_update_delay (sac.yml:44, td3.yml): actor updates every 3rd iteration
+
+
+def describe(w):
+    return (f"{'TD3' if w['td3'] else 'SAC'} {w['env']} batch={w['batch']}, 2x256 MLP + LayerNorm, {w['rows']} rows resident in a "
+            f"{w['capacity']}-row HBM replay ring, one hipGraph launch per iteration (1 critic update, 2 actor"
+            f"{'' if w['td3'] else '+alpha'} updates every 3rd, Polyak)")
 
 
 def gather_algo_bytes(o, a, batch):
@@ -31,11 +48,11 @@ def gather_algo_bytes(o, a, batch):
     return 2 * batch * (4 * (2 * o + a + 1) + 1) + 4 * batch
 
 
-def make_engine(w, seed, device_id):
+def make_engine(w, seed, device_id, rows=None, capacity=None):
     import torch
     import sac_td3_cudagraphs_pytorch_amd as pkg
     from sac_td3_cudagraphs_pytorch_amd import schema
-    cfg = pkg.Config(ob_dim=w["o"], ac_dim=w["a"], batch_size=w["batch"], rb_capacity=w["capacity"], max_envs=4,
+    cfg = pkg.Config(ob_dim=w["o"], ac_dim=w["a"], batch_size=w["batch"], rb_capacity=capacity or w["capacity"], max_envs=4,
                      prefer_td3_over_sac=w["td3"], bcq_style_targ_mix=w["td3"], qnets_lr=3e-4 if w["td3"] else 1e-3,
                      seed=seed, device_id=device_id, use_graphs=os.environ.get("SACTD3_BENCH_GRAPHS", "1") != "0")   # (0: same launches, no hipGraph)
     eng = pkg.Engine(cfg, [-w["bound"]] * w["a"], [w["bound"]] * w["a"])
@@ -43,11 +60,20 @@ def make_engine(w, seed, device_id):
     actor, critics = schema.reference_initial_params(w["o"], w["a"], w["td3"], True)
     for which, flat in ((0, actor), (2, actor), (1, critics), (3, critics)):
         eng.set_params(which, flat)
-    eng.rb_fill_synthetic(w["rows"], seed=0)  # data seed 0
+    if rows is None:
+        eng.rb_fill_synthetic(w["rows"], seed=0)  # data seed 0
     eng.sync()
     return eng
 
 
+def run_steps(eng, it, n):
+    for _ in range(n):
+        eng.step(it % (DELAY + 1) == 0)
+        it += 1
+    return it
+
+
+# ------------------------------------------------------------------------------------------------ baselines (the oracle, timed)
 def oracle_rate(w, device, seconds, threads=None, min_iters=0):
     """iterations/s of the plain-torch restatement (oracle) on `device`: the reference's CPU / eager-ROCm path."""
     import torch
@@ -150,9 +176,11 @@ def oracle_graph_rate(w, seconds):
 
 
 def parity_deltas(w, device_id, iters=6):
-    """SURVEY 8(d) 'parity deltas': `iters` iterations of the workload (same batches, same injected noise, reference
-    schedule) through the engine's call-by-call API and through the oracle; max abs difference of the reported scalars
-    and of the parameters afterwards.  Part of the baseline leg: the oracle is the checker, never the thing measured."""
+    """SURVEY 8(d) 'parity deltas' of the TIMED path: `iters` fused iterations (sactd3_step, native Philox sampling and
+    noise, graph replay) at the workload's own shapes; after each one the indices and normals the engine used are read
+    back and the oracle's iteration is driven with exactly those (the reference's draw order, agents/agent.py:205,254,298).
+    Max abs difference of the reported scalars and of the parameters afterwards.  The oracle is the checker here, never
+    the thing measured."""
     import numpy as np
     import torch
     import sac_td3_cudagraphs_pytorch_amd as pkg
@@ -163,38 +191,197 @@ def parity_deltas(w, device_id, iters=6):
     torch.manual_seed(0)
     lo, hi = [-w["bound"]] * a, [w["bound"]] * a
     ref = RefAgent(o, a, lo, hi, hps)
-    eng = pkg.Engine(pkg.Config.from_hps(hps, o, a, rb_capacity=1024, seed=0, device_id=device_id), lo, hi)
+    n = 16384
+    eng = pkg.Engine(pkg.Config.from_hps(hps, o, a, rb_capacity=n, seed=0, device_id=device_id), lo, hi)
     nh = a if td3 else 2 * a
     flat_a = lambda m: schema.dict_to_flat({k: v for k, v in m.state_dict().items() if k.startswith(("fc_stack", "head"))}, o, nh, True)
     flat_c = lambda ms: np.concatenate([schema.dict_to_flat(q.state_dict(), o + a, 1, True) for q in ms])
     eng.set_params(_lib.ACTOR, flat_a(ref.actor)); eng.set_params(_lib.ACTOR_TARGET, flat_a(ref.actor_target))
     eng.set_params(_lib.CRITICS, flat_c(ref.qnets)); eng.set_params(_lib.CRITICS_TARGET, flat_c(ref.qnets_target))
     g = torch.Generator().manual_seed(1)
+    rows = [torch.randn(n, o, generator=g).numpy(), ((torch.rand(n, a, generator=g) * 2 - 1) * w["bound"]).numpy(),
+            torch.randn(n, generator=g).numpy(), torch.randn(n, o, generator=g).numpy(), (torch.rand(n, generator=g) < 0.01).numpy()]
+    for lo_ in range(0, n, 4096):
+        eng.rb_extend(*[r[lo_:lo_ + 4096] for r in rows])
     worst = {}
     for i in range(iters):
-        obs, nobs = torch.randn(B, o, generator=g), torch.randn(B, o, generator=g)
-        act = (torch.rand(B, a, generator=g) * 2 - 1) * w["bound"]
-        rew, done = torch.randn(B, generator=g), torch.rand(B, generator=g) < 0.01
-        noise = {"critic": torch.randn(B, a, generator=g), "actor": [torch.randn(B, a, generator=g) for _ in range(2)],
-                 "alpha": [torch.randn(B, a, generator=g) for _ in range(2)]}
-        want = ref.iteration(ref.to_batch(obs, act, rew, nobs, done), i, noise)
-        eng.load_batch(obs, act, rew, nobs, done)
-        eng.set_noise(_lib.SITE_CRITIC, noise["critic"])
-        eng.update_qnets()
-        if i % (hps.actor_update_delay + 1) == 0:
-            for j in range(hps.actor_update_delay):
-                eng.set_noise(_lib.SITE_ACTOR0, noise["actor"][j]); eng.set_noise(_lib.SITE_ALPHA0, noise["alpha"][j])
-                eng.update_actor()
-        eng.update_targ_nets(i + 1)
+        do_actor = i % (DELAY + 1) == 0
+        eng.step(do_actor)
+        idx = eng.read_batch()["index"]
+        noise = {"critic": torch.from_numpy(eng.read_noise(_lib.SITE_CRITIC))}
+        if do_actor and not td3:
+            noise["actor"] = [torch.from_numpy(eng.read_noise(s)) for s in (_lib.SITE_ACTOR0, _lib.SITE_ACTOR1)]
+            noise["alpha"] = [torch.from_numpy(eng.read_noise(s)) for s in (_lib.SITE_ALPHA0, _lib.SITE_ALPHA1)]
+        want = ref.iteration(ref.to_batch(*[r[idx] for r in rows]), i, noise)
         got = eng.read_metrics()
         for k, v in want.items():
             worst[k] = max(worst.get(k, 0.0), abs(got[k] - float(v)))
     worst["params/critics"] = float(np.abs(eng.get_params(_lib.CRITICS) - flat_c(ref.qnets)).max())
     worst["params/actor"] = float(np.abs(eng.get_params(_lib.ACTOR) - flat_a(ref.actor)).max())
     eng.close()
-    return {"iterations": iters, "max_abs_delta": worst,
-            "note": "fp32 vs the plain-PyTorch oracle on the same batches and noise; parameters after the Adam steps can differ by "
-                    "up to 2 lr per step where a gradient is near zero (sign-like first steps), see tests/helpers.py"}
+    return {"path": "sactd3_step (fused iteration, graph replay, native RNG; oracle driven with the read-back indices and noise)",
+            "iterations": iters, "max_abs_delta": worst,
+            "note": "fp32 vs the plain-PyTorch oracle; parameters after the Adam steps can differ by up to 2 lr per step where a "
+                    "gradient is near zero (sign-like first steps), see tests/helpers.py"}
+
+
+# ------------------------------------------------------------------------------------------------ per-node budget and rooflines
+def _norm_kernel(name):
+    """rocprofv3's 'void k_nt<1, true, 2, 1, 2>(NtArgs)' -> 'k_nt<1,true,2,1,2>' (= the node registry's instance names)."""
+    name = re.sub(r"^void\s+", "", name.strip())
+    name = re.sub(r"\([^()]*\)\s*$", "", name)
+    return name.replace(" ", "")
+
+
+def pmc_traffic(workload):
+    """{(kernel instance, threads): HBM-side bytes per launch} from the committed rocprofv3 --pmc summaries
+    profiles/r*_pmc_<workload>.csv (written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes; the
+    gfx950 x2 correction of FETCH_SIZE is applied there, per MI355X_MICROARCH.md section HBM).  Newest round wins."""
+    out, src = {}, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload}.csv"))):
+        src = os.path.relpath(path, ROOT)
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                out[(r["kernel"], int(r["threads"]))] = dict(traffic=float(r["traffic_bytes"]), fetch=float(r["fetch_bytes"]),
+                                                             write=float(r["write_bytes"]), calls=int(r["calls"]), source=src)
+    return out
+
+
+def node_budget(w, workload, device_id, ms_per_step, iters=200):
+    """DESIGN.md section 5's budget as numbers: every kernel node of the 7- and 30-node iteration graphs timed alone
+    (HIP events on the engine's stream, un-profiled, back-to-back launches of that node on a scratch engine), the sum over
+    the reference's schedule (2 critic-only iterations + 1 with the actor updates per period) against the measured
+    ms_per_step, and the roofline of every kernel instance from its algorithmic FLOPs / bytes."""
+    eng = make_engine(w, seed=12345, device_id=device_id)
+    run_steps(eng, 0, 6)
+    eng.sync()
+    g0, g1 = eng.time_nodes(False, iters), eng.time_nodes(True, iters)
+    eng.close()
+    s0, s1 = sum(n["us"] for n in g0), sum(n["us"] for n in g1)
+    per_iter = (DELAY * s0 + s1) / (DELAY + 1)
+    traffic = pmc_traffic(workload)
+    groups = {}
+    for weight, nodes in ((DELAY / (DELAY + 1), g0), (1.0 / (DELAY + 1), g1)):
+        for n in nodes:
+            key = (n["name"].split(":")[0], n["threads"])
+            d = groups.setdefault(key, dict(us_per_iteration=0.0, launches_per_iteration=0.0, flops=n["flops"], bytes=n["bytes"], roles=[]))
+            d["us_per_iteration"] += weight * n["us"]
+            d["launches_per_iteration"] += weight
+            role = n["name"].split(":", 1)[1]
+            if role not in d["roles"]:
+                d["roles"].append(role)
+    rooflines = []
+    for (kern, threads), d in sorted(groups.items(), key=lambda kv: -kv[1]["us_per_iteration"]):
+        us = d["us_per_iteration"] / d["launches_per_iteration"]
+        t_mfma, t_hbm = d["flops"] / (MFMA_F32_PEAK_TF * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
+        tr = traffic.get((kern, threads))
+        if t_mfma >= t_hbm:
+            ach, peak, unit, bound = d["flops"] / us * 1e-6, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = d["bytes"] / us * 1e-3, HBM_PEAK_GBS, "GB/s", "hbm"
+        rooflines.append({"kernel": kern, "threads": threads, "roles": d["roles"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                          "frac": ach / peak, "traffic": tr["traffic"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                          "algo_flops_per_launch": d["flops"], "algo_bytes_per_launch": d["bytes"], "avg_launch_us": us,
+                          "launches_per_iteration": d["launches_per_iteration"], "us_per_iteration": d["us_per_iteration"],
+                          "share_of_node_time": d["us_per_iteration"] / per_iter})
+    return {"critic_only": [[n["name"], round(n["us"], 3)] for n in g0], "critic_plus_2_actor": [[n["name"], round(n["us"], 3)] for n in g1],
+            "sum_critic_only_us": s0, "sum_critic_plus_2_actor_us": s1, "sum_per_iteration_us": per_iter,
+            "measured_us_per_iteration": 1e3 * ms_per_step, "unaccounted_us_per_iteration": 1e3 * ms_per_step - per_iter,
+            "note": "each node alone, back to back (includes its ~1.5 us launch boundary); unaccounted = what the dependent chain of "
+                    "DIFFERENT kernels and the gap between graph replays add or save"}, rooflines
+
+
+def gather_cold(eng, w, iters=300):
+    """the replay gather at the workload's own batch size with a fresh index draw per launch (rows from HBM / MALL, not L2)."""
+    us = eng.time_kernel("gather", iters)
+    ab = gather_algo_bytes(w["o"], w["a"], w["batch"])
+    return {"kernel": "k_gather", "batch": w["batch"], "us_incl_counter_tick_kernel": us, "algo_bytes": ab, "GB/s": ab / us * 1e-3,
+            "frac_of_8TBs": ab / us * 1e-3 / HBM_PEAK_GBS}
+
+
+def baselines(w, value, cpu_seconds, eager_seconds, graph_seconds):
+    out = {}
+    best = None
+    for nt in (1, 8):   # torch's default of one thread per host core is slower than a few threads at these op sizes
+        v, n = oracle_rate(w, "cpu", cpu_seconds / 2, threads=nt)
+        if best is None or v > best[0]:
+            best = (v, n, nt)
+    out["cpu_baseline"] = {"value": best[0], "unit": "gradient-steps/s", "cores": best[2], "kind": "port",
+                           "sample": f"{best[1]} iterations of the same workload through oracle/sac_td3_ref.py "
+                                     f"(plain PyTorch CPU eager, torch.set_num_threads({best[2]}); faster of 1 and 8 threads)"}
+    v, n = oracle_rate(w, "cuda", eager_seconds)
+    out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
+                                  "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
+    out["speedup_vs_eager_rocm"] = value / v
+    try:
+        vg, ng = oracle_graph_rate(w, graph_seconds)
+        out["torch_cudagraph_rocm_baseline"] = {"value": vg, "unit": "gradient-steps/s",
+                                                "sample": f"{ng} iterations, same restatement, update_qnets / update_actor as "
+                                                          "torch.cuda.CUDAGraph replays (the reference's cudagraphs: true mode), sampling and target update eager"}
+        out["speedup_vs_torch_cudagraph_rocm"] = value / vg
+    except Exception as ex:   # capture support for an op can differ between torch / ROCm versions: report, do not fail the run
+        out["torch_cudagraph_rocm_baseline"] = {"value": None, "error": repr(ex)[:300]}
+    return out
+
+
+def secondary_config(name, device_id, steps=3000, warmup=300):
+    """BASELINE.json configs 3 / 4 in the same driver line: own engine, own timing, node budget, roofline, parity, baselines."""
+    import torch
+    w = WORKLOADS[name]
+    eng = make_engine(w, seed=0, device_id=device_id)
+    it = run_steps(eng, 0, warmup)
+    eng.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(eng, it, steps)
+    eng.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": describe(w), "value": steps / dt, "unit": "gradient-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+           "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
+           "final_metrics": eng.read_metrics(), "replay_gather_cold": gather_cold(eng, w)}
+    eng.close()
+    out["node_us"], rl = node_budget(w, name, device_id, out["ms_per_step"])
+    out["roofline"], out["rooflines_top"] = rl[0], rl[1:5]
+    out["parity"] = parity_deltas(w, device_id)
+    out.update(baselines(w, out["value"], cpu_seconds=6.0, eager_seconds=3.0, graph_seconds=3.0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ranks
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Parent of an N-GPU run.  NOTHING here touches the GPU (no torch import, no HIP call): the ranks are fresh child
+    processes started through torch.distributed.run, one per GPU, and this process only waits and passes on the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class _DryEngine:
+    """--dry-run-ranks: no GPU work at all.  Checks launching, rendezvous, barrier, max-over-ranks and the JSON line on a
+    box without a GPU (tests/test_launcher_gloo.py); the line it prints is marked dry_run and carries no measurement."""
+
+    def step(self, do_actor):
+        time.sleep(1e-4)
+
+    def sync(self):
+        pass
+
+    def read_metrics(self):
+        return {}
+
+    def graph_kernel_count(self, which):
+        return 0
+
+    def close(self):
+        pass
 
 
 def main():
@@ -204,13 +391,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="hopper_sac", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-baselines", action="store_true")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the baselines, the other configs and the extra figures")
+    ap.add_argument("--timed-only", action="store_true", help="only the warm-up and the timed steps (rocprofv3 runs)")
+    ap.add_argument("--dry-run-ranks", action="store_true", help="no GPU work: rehearse rank launching / rendezvous / aggregation on CPU")
     ap.add_argument("--eager-profile", type=int, default=0, metavar="ITERS",
                     help="run ONLY the eager PyTorch-ROCm restatement for ITERS iterations (for rocprofv3 launch counts)")
     ap.add_argument("--gather-profile", type=int, default=0, metavar="BATCH",
                     help="run ONLY the replay gather at this batch size 20 times (for rocprofv3 --pmc traffic counters)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.eager_profile:
         v, n = oracle_rate(w, "cuda", 0.0, min_iters=args.eager_profile)
         print(json.dumps({"eager_rocm_iterations": n, "rate": v}))
@@ -225,35 +416,32 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     import torch
     # rehearsal knobs (one-GPU boxes): SACTD3_BENCH_BACKEND=gloo and SACTD3_BENCH_DEVICE=0 let N ranks share one card
-    backend = os.environ.get("SACTD3_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("SACTD3_BENCH_BACKEND", "gloo" if args.dry_run_ranks else "nccl")
     if "SACTD3_BENCH_DEVICE" in os.environ:
         local = int(os.environ["SACTD3_BENCH_DEVICE"])
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    gpu_sync = (lambda: None) if args.dry_run_ranks else torch.cuda.synchronize
 
-    eng = make_engine(w, seed=rank, device_id=local)  # seed = GPU index, one independent learner per GPU
-    delay = 2
-    it = 0
-    for _ in range(args.warmup):
-        eng.step(it % (delay + 1) == 0)
-        it += 1
+    # seed = GPU index, one independent learner per GPU
+    eng = _DryEngine() if args.dry_run_ranks else make_engine(w, seed=rank, device_id=local)
+    it = run_steps(eng, 0, args.warmup)
     eng.sync()
-    torch.cuda.synchronize()
+    gpu_sync()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(it % (delay + 1) == 0)
-        it += 1
+    it = run_steps(eng, it, args.steps)
     eng.sync()
-    torch.cuda.synchronize()
+    gpu_sync()
     dt = time.perf_counter() - t0
     if dist:
         t = torch.tensor([dt], device=red_dev)
@@ -268,130 +456,118 @@ def main():
             "value": world * args.steps / dt, "unit": "gradient-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'TD3' if w['td3'] else 'SAC'} {w['env']} batch={w['batch']}, 2x256 MLP + LayerNorm, "
-                                   f"{w['rows']} rows resident in a {w['capacity']}-row HBM replay ring, "
-                                   "one hipGraph launch per iteration (1 critic update, 2 actor+alpha updates every 3rd, Polyak)",
-                       "parallelism": f"{world} independent seeds, one per GPU, no collective"},
+            "config": {"workload": describe(w), "parallelism": f"{world} independent seeds, one per GPU, no collective"},
             # one iteration = 1 critic update (+ Polyak) and, every 3rd iteration, 2 actor(+alpha) updates
             "critic_updates_per_s": world * args.steps / dt, "actor_updates_per_s": world * args.steps / dt * 2.0 / 3.0,
             "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
             "final_metrics": metrics,
         }
-        # roofline of the replay gather (the path's HBM-bound kernel; north_star's "replay HBM GB/s"):
-        # algorithmic bytes per launch / average launch duration from HIP events on the engine's stream
-        us = eng.time_kernel("gather", 2000)
-        ab = gather_algo_bytes(w["o"], w["a"], w["batch"])
-        out["roofline"] = {"kernel": "k_gather", "bound": "hbm", "achieved": ab / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ab / us * 1e-3 / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": ab, "avg_launch_us": us,
-                           "note": "B=256 is launch/latency-bound by construction; see gather_batch_sweep for the bandwidth end "
-                                   "and profiles/r01_gather_humanoid_b65536_pmc.csv for the PMC traffic (1.01x algorithmic)"}
-        # the kernel that takes the most time: hidden layers of the 4 critics (fp32 MFMA); FLOPs = 2*MAC of both layers
-        us_t = eng.time_kernel("trunk_critics", 500)
-        fl = 4 * 2.0 * w["batch"] * 256 * ((w["o"] + w["a"]) + 256)
-        out["roofline_mfma"] = {"kernel": "k_nt (4-net critic trunk)", "bound": "mfma", "achieved": fl / us_t * 1e-6, "peak": 157.3,
-                                "unit": "TFLOP/s", "frac": fl / us_t * 1e-6 / 157.3, "flops_per_launch": fl, "avg_launch_us": us_t}
-        # acting side (agents/agent.py:172-181): one predict round trip = H2D of the observations, 2 kernels, D2H + sync
-        import numpy as np
-        ob = np.zeros((4, w["o"]), np.float32)
-        for _ in range(20):
-            eng.predict(ob, True)
-        tp = time.perf_counter()
-        for _ in range(300):
-            eng.predict(ob, True)
-        out["predict_round_trip_us"] = (time.perf_counter() - tp) / 300 * 1e6
-        # rb.extend of one env step (num_envs = 4 rows, orchestrator.py:100-113): host pack + async H2D + length publish
-        rows = [np.zeros((4, w["o"]), np.float32), np.zeros((4, w["a"]), np.float32), np.zeros(4, np.float32),
-                np.zeros((4, w["o"]), np.float32), np.zeros(4, bool)]
-        for _ in range(700):   # (the HIP runtime grows its signal pools during the first few hundred async copies)
-            eng.rb_extend(*rows)
-        eng.sync()
-        tp = time.perf_counter()
-        for _ in range(300):
-            eng.rb_extend(*rows)
-        eng.sync()
-        out["rb_extend_call_us"] = (time.perf_counter() - tp) / 300 * 1e6
-        # SURVEY 8(d)'s optional second figure: the loop as orchestrator.py:325-352 runs it, minus the simulator -- per
-        # iteration one synchronous predict for the 4 envs, one rb.extend of their 4 transitions, one fused update
-        tp = time.perf_counter()
-        for i in range(600):
-            eng.predict(ob, True)
-            eng.rb_extend(*rows)
-            eng.step(i % 3 == 0)
-        eng.sync()
-        out["loop_with_acting_per_s"] = 600 / (time.perf_counter() - tp)
-        if world == 1 and not args.no_baselines:
-            # Seed sweeps are the reference's unit of work (spawner.py: one job per seed) and one learner leaves most of an
-            # MI355X idle: S independent engines (own stream, own graphs, seeds 0..S-1) in this process, one host thread each,
-            # aggregate gradient-steps/s.  An extra figure -- `value` above stays the one-learner-per-GPU number.
-            multi = {}
-            for S in (2, 4, 8):
-                engs = [eng] + [make_engine(w, seed=100 + k, device_id=local) for k in range(1, S)]
-                for i in range(150):
-                    for e2 in engs:
-                        e2.step(i % 3 == 0)
-                for e2 in engs:
-                    e2.sync()
-                import threading
-
-                def drive(e2):                              # one host thread per learner (ctypes drops the GIL in the call)
-                    for i in range(600):
-                        e2.step(i % 3 == 0)
-                    e2.sync()
-                th = [threading.Thread(target=drive, args=(e2,)) for e2 in engs]
-                tp = time.perf_counter()
-                for x in th:
-                    x.start()
-                for x in th:
-                    x.join()
-                multi[str(S)] = S * 600 / (time.perf_counter() - tp)
-                for e2 in engs[1:]:
-                    e2.close()
-            out["learners_per_gpu_aggregate_steps_per_s"] = multi
-            # large-batch asymptote of the same kernel (B=256 is launch-bound by construction)
-            sweep = {}
-            for bs in (256, 4096, 65536):
-                us_b, by = eng.time_gather_sweep(bs, 200 if bs < 65536 else 50)
-                sweep[str(bs)] = {"us": us_b, "GB/s": by / us_b * 1e-3}
-            out["gather_batch_sweep"] = sweep
-            eng.close()
-            # north_star's "replay-gather HBM GB/s as fraction of 8 TB/s": the same kernel on the Humanoid-v4 record
-            # (3136 B/row) out of a full 1M-row (3.1 GB, far beyond the 256 MB Infinity Cache) ring, 65 536 rows per launch
-            wh = WORKLOADS["humanoid_sac"]
-            eh = make_engine(wh, 0, local)
-            us_h, by_h = eh.time_gather_sweep(65536, 50)
-            out["replay_gather_hbm"] = {"record": "Humanoid-v4 (o=376, a=17), 1M-row ring", "rows_per_launch": 65536, "us": us_h,
-                                        "algo_bytes": by_h, "achieved": by_h / us_h * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": by_h / us_h * 1e-3 / HBM_PEAK_GBS,
-                                        "traffic": 409.8e6, "traffic_unit": "bytes per launch",
-                                        "traffic_note": "PMC: FETCH_SIZE 103 539 KB x2 (gfx950 correction) + WRITE_SIZE 202 715 KB, separate --pmc passes, "
-                                                        "profiles/r01_gather_humanoid_b65536_pmc.csv = 1.01x the algorithmic bytes"}
-            eh.close()
-            # the op sizes are tiny: torch's default of one thread per host core (128 here) is slower than a few threads,
-            # so time 1 and 8 threads on a bounded sample each and report the faster one
-            best = None
-            for nt in (1, 8):
-                v, n = oracle_rate(w, "cpu", args.cpu_seconds / 2, threads=nt)
-                if best is None or v > best[0]:
-                    best = (v, n, nt)
-            out["cpu_baseline"] = {"value": best[0], "unit": "gradient-steps/s", "cores": best[2], "kind": "port",
-                                   "sample": f"{best[1]} iterations of the same workload through oracle/sac_td3_ref.py "
-                                             f"(plain PyTorch CPU eager, torch.set_num_threads({best[2]}); faster of 1 and 8 threads)"}
-            out["parity"] = parity_deltas(w, local)
-            v, n = oracle_rate(w, "cuda", 6.0)
-            out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
-                                          "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
-            out["speedup_vs_eager_rocm"] = out["value"] / v
-            try:
-                vg, ng = oracle_graph_rate(w, 4.0)
-                out["torch_cudagraph_rocm_baseline"] = {"value": vg, "unit": "gradient-steps/s",
-                                                        "sample": f"{ng} iterations, same restatement, update_qnets / update_actor as "
-                                                                  "torch.cuda.CUDAGraph replays (the reference's cudagraphs: true mode), sampling and target update eager"}
-                out["speedup_vs_torch_cudagraph_rocm"] = out["value"] / vg
-            except Exception as ex:   # capture support for an op can differ between torch / ROCm versions: report, do not fail the run
-                out["torch_cudagraph_rocm_baseline"] = {"value": None, "error": repr(ex)[:300]}
+        if args.dry_run_ranks:
+            out.update(dry_run=True, value=None, note="no GPU work was done: rank launching / rendezvous / aggregation rehearsal only")
+        elif not args.timed_only:
+            extras(out, eng, w, args, local, world)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def extras(out, eng, w, args, local, world):
+    """Everything in the line beyond the timed steps (rank 0): rooflines, node budget, acting-side figures, the other
+    BASELINE configs, baselines.  None of it is inside the timed region above."""
+    import numpy as np
+    # a longer window of the same loop (the driver's 20-step window is ~1.7 ms): agreement check for `value`
+    it = run_steps(eng, 0, 300)
+    eng.sync()
+    tp = time.perf_counter()
+    run_steps(eng, it, 3000)
+    eng.sync()
+    out["value_3000_steps"] = 3000 / (time.perf_counter() - tp)
+    out["replay_gather_cold"] = gather_cold(eng, w)
+    # acting side (agents/agent.py:172-181): one predict round trip = H2D of the observations, 2 kernels, D2H + sync
+    ob = np.zeros((4, w["o"]), np.float32)
+    for _ in range(20):
+        eng.predict(ob, True)
+    tp = time.perf_counter()
+    for _ in range(300):
+        eng.predict(ob, True)
+    out["predict_round_trip_us"] = (time.perf_counter() - tp) / 300 * 1e6
+    # rb.extend of one env step (num_envs = 4 rows, orchestrator.py:100-113): host pack + async H2D + length publish
+    rows = [np.zeros((4, w["o"]), np.float32), np.zeros((4, w["a"]), np.float32), np.zeros(4, np.float32),
+            np.zeros((4, w["o"]), np.float32), np.zeros(4, bool)]
+    for _ in range(700):   # (the HIP runtime grows its signal pools during the first few hundred async copies)
+        eng.rb_extend(*rows)
+    eng.sync()
+    tp = time.perf_counter()
+    for _ in range(300):
+        eng.rb_extend(*rows)
+    eng.sync()
+    out["rb_extend_call_us"] = (time.perf_counter() - tp) / 300 * 1e6
+    # SURVEY 8(d)'s optional second figure: the loop as orchestrator.py:325-352 runs it, minus the simulator -- per
+    # iteration one synchronous predict for the 4 envs, one rb.extend of their 4 transitions, one fused update
+    tp = time.perf_counter()
+    for i in range(600):
+        eng.predict(ob, True)
+        eng.rb_extend(*rows)
+        eng.step(i % 3 == 0)
+    eng.sync()
+    out["loop_with_acting_per_s"] = 600 / (time.perf_counter() - tp)
+    if world != 1 or args.no_baselines:
+        eng.close()
+        return
+    # Seed sweeps are the reference's unit of work (spawner.py: one job per seed) and one learner leaves most of an
+    # MI355X idle: S independent engines (own stream, own graphs, seeds 0..S-1) in this process, one host thread each,
+    # aggregate gradient-steps/s.  An extra figure -- `value` above stays the one-learner-per-GPU number.
+    import threading
+    multi = {}
+    for S in (2, 4, 8):
+        engs = [eng] + [make_engine(w, seed=100 + k, device_id=local) for k in range(1, S)]
+        for i in range(150):
+            for e2 in engs:
+                e2.step(i % 3 == 0)
+        for e2 in engs:
+            e2.sync()
+
+        def drive(e2):                              # one host thread per learner (ctypes drops the GIL in the call)
+            for i in range(600):
+                e2.step(i % 3 == 0)
+            e2.sync()
+        th = [threading.Thread(target=drive, args=(e2,)) for e2 in engs]
+        tp = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        multi[str(S)] = S * 600 / (time.perf_counter() - tp)
+        for e2 in engs[1:]:
+            e2.close()
+    out["learners_per_gpu_aggregate_steps_per_s"] = multi
+    # large-batch asymptote of the gather (B=256 is launch-bound by construction, SURVEY.md 7.2)
+    sweep = {}
+    for bs in (256, 4096, 65536):
+        us_b, by = eng.time_gather_sweep(bs, 200 if bs < 65536 else 50)
+        sweep[str(bs)] = {"us": us_b, "GB/s": by / us_b * 1e-3}
+    out["gather_batch_sweep"] = sweep
+    eng.close()
+    # roofline of the DOMINANT kernel of the timed graph (largest share of the iteration's node time), and the others
+    out["node_us"], rl = node_budget(w, args.workload, local, out["ms_per_step"])
+    out["roofline"], out["rooflines_top"] = rl[0], rl[1:5]
+    # north_star's "replay-gather HBM GB/s as fraction of 8 TB/s": the same kernel on the Humanoid-v4 record
+    # (3136 B/row) out of a full 1M-row (3.1 GB, far beyond the 256 MB Infinity Cache) ring, 65 536 rows per launch
+    wh = WORKLOADS["humanoid_sac"]
+    eh = make_engine(wh, 0, local)
+    us_h, by_h = eh.time_gather_sweep(65536, 50)
+    trs = [v for (k, _), v in sorted(pmc_traffic("gather_humanoid_b65536").items(), key=lambda kv: kv[0][1]) if k == "k_gather"]
+    tr = trs[-1] if trs else None     # the 65 536-row launches (largest grid) of profiles/r*_pmc_gather_humanoid_b65536.csv
+    out["replay_gather_hbm"] = {"record": "Humanoid-v4 (o=376, a=17), 1M-row ring", "rows_per_launch": 65536, "us": us_h,
+                                "algo_bytes": by_h, "achieved": by_h / us_h * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": by_h / us_h * 1e-3 / HBM_PEAK_GBS, "bound": "hbm",
+                                "traffic": tr["traffic"] if tr else None, "traffic_unit": "bytes per launch",
+                                "traffic_source": tr["source"] if tr else None}
+    eh.close()
+    out["parity"] = parity_deltas(w, local)
+    out.update(baselines(w, out["value"], cpu_seconds=args.cpu_seconds, eager_seconds=6.0, graph_seconds=4.0))
+    # BASELINE.json configs 3 and 4, each measured the same way (own 3000 timed steps)
+    out["configs"] = {name: secondary_config(name, local) for name in ("halfcheetah_td3", "humanoid_sac") if name != args.workload}
 
 
 if __name__ == "__main__":

@@ -171,9 +171,16 @@ const char* sactd3_debug_names(void);
 /* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1) */
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph);
 /* average device time in microseconds of `iters` back-to-back launches of one kernel of the path,
- * measured with hipEvents on the engine's stream: "gather", "polyak", "trunk_critics" (the 4-net hidden-layer
- * launch of update_qnets; on wide inputs it is two launches). [sync] */
+ * measured with hipEvents on the engine's stream: "gather" (a fresh index draw per launch), "polyak", "trunk_critics" (the 4-net
+ * hidden-layer launch of update_qnets; on wide inputs it is two launches). [sync] */
 int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec);
+/* Per-node device time of one fused iteration (sactd3_step with this do_actor): every kernel launch of the sequence
+ * alone, `iters` times back to back between two HIP events on the engine's stream.  Returns the node count n (<= max_nodes)
+ * and fills usec[n], flops[n] (2 x MACs of the GEMMs in the launch), bytes[n] (operands + results, each once),
+ * threads[n] (grid x block, rocprofv3's Grid_Size); `names` receives n newline-terminated "kernel-instance:role" strings.  Consumes the learner's state (optimiser steps repeat on
+ * stale gradients): call it on a scratch engine.  Stands in for nothing in the reference: SURVEY.md 8d measurement. [sync] */
+int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, char* names, int names_cap,
+                      float* usec, double* flops, double* bytes, int64_t* threads);
 /* run the replay gather at an arbitrary batch size (<= max set at create via env SACTD3_SWEEP_MAX_B) */
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes);
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sactd3_read_batch", "sactd3_rb_fill_synthetic", "sactd3_set_noise", "sactd3_clear_noise", "sactd3_read_noise",
     "sactd3_update_qnets", "sactd3_update_actor", "sactd3_update_targ_nets", "sactd3_step", "sactd3_predict",
     "sactd3_read_metrics", "sactd3_sync", "sactd3_debug_read", "sactd3_debug_names", "sactd3_graph_kernel_count",
-    "sactd3_time_kernel", "sactd3_time_gather_sweep",
+    "sactd3_time_kernel", "sactd3_time_gather_sweep", "sactd3_time_nodes",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library():
         "sactd3_graph_kernel_count": (C.c_int, [vp, C.c_int]),
         "sactd3_time_kernel": (C.c_int, [vp, C.c_char_p, C.c_int, fp]),
         "sactd3_time_gather_sweep": (C.c_int, [vp, C.c_int, C.c_int, fp, C.POINTER(C.c_double)]),
+        "sactd3_time_nodes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64p]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -95,7 +95,9 @@ class Agent:
 
     def __init__(self, net_shapes: Dict[str, tuple], min_ac: np.ndarray, max_ac: np.ndarray, device: Any,
                  hps: Any, rb: Optional[ReplayBuffer] = None, *, seed: Optional[int] = None,
-                 init_params: bool = True):
+                 init_params: bool = True, use_graphs: Optional[bool] = None):
+        """`use_graphs`: None = the engine's own hipGraphs ON (whatever `hps.cudagraphs` says: that key steers the reference
+        loop's CudaGraphModule wrappers, orchestrator.py:313-315, which must stay off around these methods)."""
         ob_dim, ac_dim = int(net_shapes["ob_shape"][-1]), int(net_shapes["ac_shape"][-1])
         self.device, self.hps = device, hps
         self.min_ac, self.max_ac = np.asarray(min_ac, np.float32), np.asarray(max_ac, np.float32)
@@ -109,6 +111,8 @@ class Agent:
             over["seed"] = int(seed)
         if rb is not None:
             over["rb_capacity"] = rb.capacity
+        if use_graphs is not None:
+            over["use_graphs"] = bool(use_graphs)
         cfg = Config.from_hps(hps, ob_dim, ac_dim, **over)
         assert getattr(hps, "segment_len", 1) <= cfg.batch_size  # agents/agent.py:47
         self.ob_dim, self.ac_dim, self.td3, self.ln = ob_dim, ac_dim, cfg.prefer_td3_over_sac, cfg.layer_norm

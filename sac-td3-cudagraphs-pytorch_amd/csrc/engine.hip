@@ -76,6 +76,8 @@ static const int BIG_BATCH = 1024;   // from here on the hidden layers run as 64
 enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_COUNT = 6 };
 static const int NSTAGE = 32;
 
+struct NodeInfo { std::string name; double flops; double bytes; long threads; };
+
 struct sactd3_engine {
   sactd3_config cfg{};
   std::string err;
@@ -115,6 +117,14 @@ struct sactd3_engine {
 
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
+  // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0;
+  // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
+  // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
+  // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
+  int node_seq = 0, node_only = -1;
+  const char* node_role = "";                 // which part of the iteration is being enqueued (names the nodes)
+  std::vector<NodeInfo>* node_log = nullptr;
 
   int fail(int code, const char* what, hipError_t he = hipSuccess) {
     err = what;
@@ -127,6 +137,12 @@ struct sactd3_engine {
   do {                                                                 \
     hipError_t _he = (call);                                           \
     if (_he != hipSuccess) return e->fail(SACTD3_EHIP, #call, _he);    \
+  } while (0)
+// every entry point runs against the engine's own device, whatever the calling thread's current device is
+#define USE_DEVICE(e)                                                                        \
+  do {                                                                                       \
+    hipError_t _he = hipSetDevice((e)->cfg.device_id);                                       \
+    if (_he != hipSuccess) return (e)->fail(SACTD3_EHIP, "hipSetDevice", _he);               \
   } while (0)
 #define RCCHK(call)                    \
   do {                                 \
@@ -154,6 +170,31 @@ static int halloc(sactd3_engine* e, T** p, size_t count) {
 }
 
 // ------------------------------------------------------------------------------------------------ launches
+// Every kernel launch of the update path is numbered here (see sactd3_engine::node_seq).  flops = 2 x MACs of the GEMMs
+// the launch contains (SURVEY.md 8d counts GEMM FLOPs only); bytes = the operands it has to read and the results it has
+// to write, each counted once (what a perfect cache hierarchy would move).
+// `name` = "<kernel instance as rocprofv3 prints it, without blanks>[.detail]"; logged as "instance:role[/detail]" with
+// the launch's total thread count (what rocprofv3 calls Grid_Size), so that a profile row can be matched to a node.
+static inline bool node_on(sactd3_engine* e, const char* name, double flops, double bytes, dim3 grid, dim3 block) {
+  if (e->node_only < 0 && !e->node_log) return true;      // the normal case: not being timed
+  const int k = e->node_seq++;
+  if (e->node_log) {
+    std::string n(name), detail;
+    const size_t dot = n.find('.');
+    if (dot != std::string::npos) { detail = "/" + n.substr(dot + 1); n.resize(dot); }
+    e->node_log->push_back(NodeInfo{n + ":" + e->node_role + detail, flops, bytes,
+                                    (long)grid.x * grid.y * grid.z * block.x * block.y * block.z});
+  }
+  return e->node_only < 0 || e->node_only == k;
+}
+#define LAUNCH(name, flops, bytes, kernel, grid, block, ...)                \
+  do {                                                                      \
+    if (node_on(e, name, flops, bytes, grid, block)) {                      \
+      hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);           \
+      HIPCHK(hipGetLastError());                                            \
+    }                                                                       \
+  } while (0)
+
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
 // one float4 chunk per thread while that still fills the chip; GATHER_CPT chunks (loads in flight) per thread beyond
@@ -192,22 +233,36 @@ static void launch_nt_f1(hipStream_t s, int ks, int nt, dim3 grid, const NtArgs&
 }
 // pro == 0: the generic-K form (unfused first layer).  Otherwise K == 256 and the block shape (16 / 32 / 64 rows x 16
 // columns) is chosen so that the launch has about one block per CU.
-static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const NtArgs& g, int nets) {
+static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro, bool fuse1, const NtArgs& g, int nets) {
   const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
+  // algorithmic work: the (fused) first layer + this layer; operands: input rows, the weight blocks, the output (+ stored activations)
+  const double fl = 2.0 * nets * (double)g.M * g.N * (g.K + (fuse1 ? g.K1 : 0));
+  double by = 4.0 * ((double)nets * g.N * (g.K + 3) + (double)nets * g.M * g.N);
+  by += fuse1 ? 4.0 * ((double)nets * HID * (g.K1 + 1) + (double)(nets / g.npg) * g.M * g.K1) : 4.0 * (double)nets * g.M * g.K;
+  for (int i = 0; i < nets / g.npg; ++i) by += 4.0 * g.npg * (double)g.M * HID * ((g.g[i].xh_out ? 1 : 0) + (g.g[i].h_out ? 1 : 0));
+  if (g.gblocks) by += 8.0 * (double)g.ga.B * 4 * (g.ga.cx + g.ga.cn + 1);
   if (pro == 0) {
-    hipLaunchKernelGGL(k_nt_wide, dim3((unsigned)(tiles_m * tiles_n), 1, (unsigned)nets), dim3(256), 0, s, g);
+    const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)nets);
+    if (!node_on(e, "k_nt_wide.layer1", fl, by, grid, dim3(256))) return 0;
+    hipLaunchKernelGGL(k_nt_wide, grid, dim3(256), 0, s, g);
   } else {
     const int tiles = tiles_m * tiles_n * nets;
     int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
-    if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) ks = v; }   // tuning aid
+    if (e->tune_ks) ks = e->tune_ks;
     const int rb = 64 / ks;
     // two column tiles per block when the launch would otherwise put two rounds of blocks on every CU: the fused first
     // layer is then recomputed (or the A rows fetched and normalised) by half as many blocks
     int nt = (ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
-    if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) nt = 1; }   // tuning aid
+    if (e->tune_nt == 1) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0)), 1, (unsigned)nets);
+    char inst[64] = "k_nt";
+    if (e->node_log) {
+      const int c1 = (g.K1 + 15) / 16;
+      snprintf(inst, sizeof(inst), "k_nt<%d,%s,%d,%d,%d>.%s", pro, fuse1 ? "true" : "false", ks, fuse1 ? (c1 <= 1 ? 1 : (c1 == 2 ? 2 : 4)) : 0, nt, name);
+    }
+    if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
     if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, nt, grid, gg); else launch_nt_f1<2>(s, ks, nt, grid, gg); }
     else if (nt == 2) {   // (KS == 2) the A rows are fetched and normalised by half as many blocks
       if (pro == 1) hipLaunchKernelGGL((k_nt<1, false, 2, 0, 2>), grid, dim3(256), 0, s, gg);
@@ -217,13 +272,13 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, int pro, bool fuse1, const
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_nn(sactd3_engine* e, hipStream_t s, const NnArgs& g, int nets) {
+static int launch_nn(sactd3_engine* e, hipStream_t s, const char* name, const NnArgs& g, int nets) {
   const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 15) / 16)), 1, (unsigned)nets);
-  hipLaunchKernelGGL(k_nn, grid, dim3(256), 0, s, g);
-  HIPCHK(hipGetLastError());
+  LAUNCH(name, 2.0 * nets * (double)g.M * HID * g.Kout, 4.0 * nets * ((double)g.M * HID + (double)HID * g.Kout + (double)g.M * g.Kout),
+         k_nn, grid, dim3(256), g);
   return 0;
 }
-static int launch_tn(sactd3_engine* e, hipStream_t s, TnArgs& g, int nets) {
+static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets) {
   auto count = [&](int kt) {
     int tiles = 0;
     for (int i = 0; i < g.nprob; ++i) {
@@ -235,8 +290,18 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, TnArgs& g, int nets) {
   // two k tiles per block (one dY slice fetched and transposed for both) once single tiles would be more than two blocks per CU
   // (the critics' launch at B = 256: 544 blocks -> 288, -0.6 us per iteration)
   int kt = (count(1) * nets > 2 * e->num_cus && g.M < BIG_BATCH) ? 2 : 1;   // (measured: no gain with a thousand rows per tile)
-  if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) kt = v; }   // tuning aid
+  if (e->tune_tn_kt) kt = e->tune_tn_kt;
   const int tiles = count(kt);
+  // dW = dY^T X of every problem; operands dY, X once each; the weight block's gradient written, and with the fused
+  // optimiser step p, m, v read and written (+ the Polyak target): 4 (g) + 24 (Adam) + 8 (Polyak) bytes per parameter
+  double fl = 0.0, by = 0.0;
+  for (int i = 0; i < g.nprob; ++i) {
+    fl += 2.0 * nets * (double)g.M * g.pr[i].N * g.pr[i].K;
+    by += 4.0 * nets * (double)g.M * (g.pr[i].N + g.pr[i].K) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
+  }
+  char inst[96];
+  snprintf(inst, sizeof(inst), "k_tn<%d>.%s", kt, name);
+  if (!node_on(e, inst, fl, by, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256))) return 0;
   if (kt == 2) hipLaunchKernelGGL(k_tn<2>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(k_tn<1>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
@@ -269,8 +334,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   const int nets = ngrp * npg;
   const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4;
   if (tk.alpha && (big_path || K > 64)) {   // only the fused-first-layer launch can carry it: otherwise its own node, first
-    hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, *tk.alpha);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_alpha_step", 0.0, 4.0 * M, k_alpha_step, dim3(1), dim3(256), *tk.alpha);
   }
   // MFMA-bound sizes with enough 64 x 64 tiles to fill the chip: tiled GEMM -> LayerNorm row kernel -> tiled GEMM
   if (big_path) {
@@ -280,8 +344,9 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
     g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
     const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64) * nets));
-    hipLaunchKernelGGL((k_nt64<4, 2, 2>), grid, dim3(512), 0, s, g);
-    HIPCHK(hipGetLastError());
+    const double by_w = 4.0 * nets * (double)HID, by_rows = 4.0 * nets * (double)M * HID;
+    LAUNCH("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
+           (k_nt64<4, 2, 2>), grid, dim3(512), g);
     LnFwd l{};
     l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
     for (int i = 0; i < ngrp; ++i) {
@@ -289,14 +354,16 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
       l.h[i] = grp[i].h ? grp[i].h : e->s_h1 + (size_t)i * npg * M * HID;
       l.xh[i] = grp[i].xh; l.rstd[i] = grp[i].rstd;
     }
-    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((M + 15) / 16), (unsigned)nets), dim3(256), 0, s, l);
-    HIPCHK(hipGetLastError());
+    {
+      double st = 1.0;   // rows written: h always, xhat where the caller keeps it
+      for (int i = 0; i < ngrp; ++i) st += grp[i].xh ? 1.0 / ngrp : 0.0;
+      LAUNCH("k_ln_fwd", 0.0, by_rows * (1.0 + st), k_ln_fwd, dim3((unsigned)((M + 15) / 16), (unsigned)nets), dim3(256), l);
+    }
     NtArgs h2{};
     h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
     h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
     for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
-    hipLaunchKernelGGL((k_nt64<4, 2, 2>), grid, dim3(512), 0, s, h2);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_nt64<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 1) + 2.0 * by_rows, (k_nt64<4, 2, 2>), grid, dim3(512), h2);
     return 0;
   }
   if (K <= 64) {
@@ -309,7 +376,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
       h.ring_rows = 1; h.ring_off = e->ldc; h.ga = gather_args(e, e->ring, -1);
       h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
     }
-    return launch_nt(e, s, pro, true, h, nets);
+    return launch_nt(e, s, "layers1+2", pro, true, h, nets);
   }
   NtArgs g{};
   g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
@@ -318,12 +385,12 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
   if (M >= BIG_BATCH && M == e->B) {   // large batch, too few nets for 64 x 64 tiles to fill the chip: 32 x 32 LDS-tiled form
     const dim3 grid((unsigned)(((M + 31) / 32) * (HID / 32) * nets));
-    hipLaunchKernelGGL((k_nt64<2, 2, 1>), grid, dim3(256), 0, s, g);
-    HIPCHK(hipGetLastError());
-  } else RCCHK(launch_nt(e, s, 0, false, g, nets));
+    LAUNCH("k_nt64<2,2,1>.layer1", 2.0 * nets * (double)M * HID * K, 4.0 * (nets * (double)HID * (K + 1) + ngrp * (double)M * K + nets * (double)M * HID),
+           (k_nt64<2, 2, 1>), grid, dim3(256), g);
+  } else RCCHK(launch_nt(e, s, "layer1", 0, false, g, nets));
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
-  return launch_nt(e, s, pro, false, h, nets);
+  return launch_nt(e, s, "layer2", pro, false, h, nets);
 }
 
 static ActorTail tail_args(sactd3_engine* e, const float* z2, const float* P, int M, int mode, int train,
@@ -340,15 +407,17 @@ static ActorTail tail_args(sactd3_engine* e, const float* z2, const float* P, in
   return t;
 }
 static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
-  hipLaunchKernelGGL(k_actor_tail, dim3((t.B + 15) / 16), dim3(256), 0, s, t);
-  HIPCHK(hipGetLastError());
+  const int nh = t.L.nh;
+  LAUNCH("k_actor_tail", 2.0 * t.B * (double)HID * nh,
+         4.0 * ((double)t.B * HID * (t.train ? 3 : 1) + (double)nh * (HID + 1) + 2.0 * HID + (double)t.B * (3 * t.a + 2) + (t.obs_src ? 2.0 * t.B * t.o : 0.0)),
+         k_actor_tail, dim3((t.B + 15) / 16), dim3(256), t);
   return 0;
 }
 
 static int enqueue_gather(sactd3_engine* e, hipStream_t s, const float* ring, int identity_len) {
   const GatherArgs g = gather_args(e, ring, identity_len);
-  hipLaunchKernelGGL(k_gather, dim3(gather_blocks((long)e->B * e->rec4)), dim3(256), 0, s, g);
-  HIPCHK(hipGetLastError());
+  // 2 B T + 4 B, T = 4 (2o + a + 1) + 1
+  LAUNCH("k_gather", 0.0, 2.0 * e->B * (4.0 * (2 * e->o + e->a + 1) + 1.0) + 4.0 * e->B, k_gather, dim3(gather_blocks((long)e->B * e->rec4)), dim3(256), g);
   return 0;
 }
 
@@ -360,8 +429,7 @@ static AdamArgs adam_args(sactd3_engine* e, float* p, const float* g, float* m, 
 }
 static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
   const int blocks = (int)std::min<long>(512, (a.n / 4 + 255) / 256);
-  hipLaunchKernelGGL(k_adam, dim3(std::max(blocks, 1)), dim3(256), 0, s, a);
-  HIPCHK(hipGetLastError());
+  LAUNCH("k_adam", 0.0, 28.0 * a.n, k_adam, dim3(std::max(blocks, 1)), dim3(256), a);
   return 0;
 }
 
@@ -374,6 +442,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   const long BH = (long)B * HID;
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
+  e->node_role = fused_sample ? "critic/next-action+sample" : "critic/next-action";
   {
     const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
     const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
@@ -390,30 +459,30 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
      //  ROCm 7.2 -- cross-stream edges are far dearer than the 1.7 us of a linear edge -- so graphs stay linear.)
     const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
                            {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
+    e->node_role = "critic/twin-q(2 target + 2 online)";
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
   }
+  e->node_role = "critic/loss+backward";
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
     t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.pstride = e->nblk4;
-    hipLaunchKernelGGL(k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), 0, s, t);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_critic_tail<16>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), t);
   }
   {  // dh1 = dz2 W2
     NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
-    RCCHK(launch_nn(e, s, g, 2));
+    RCCHK(launch_nn(e, s, "k_nn.dh1", g, 2));
   }
   {
     LnBwd l{};
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = ln;
     l.dz = e->c_dz1; l.part = e->part; l.pstride = e->nblk4;
-    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, 2), dim3(256), 0, s, l);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_ln_bwd<16>", 0.0, 4.0 * 2 * (4.0 * BH + B + HID), k_ln_bwd<16>, dim3(e->nblk, 2), dim3(256), l);
   }
   {  // every critic gradient + the Adam step (+ Polyak) in one launch:
      //   dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead ; dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
@@ -429,7 +498,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
     g.loss_part = e->part_s; g.loss_n = 2 * e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;   // unused tail entries stay 0
     g.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS]; g.tick = &e->ctl->noise_ctr;
-    RCCHK(launch_tn(e, s, g, 2));
+    RCCHK(launch_tn(e, s, fused_polyak_targ ? "dW+adam+polyak" : "dW+adam", g, 2));
   }
   return 0;
 }
@@ -443,6 +512,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
   const bool clip = c.clip_norm > 0.f;
+  e->node_role = (j & 1) ? "actor1/policy" : "actor0/policy";
   if (!head_done) {  // a_pi, logp = pi(s) with stores for the backward pass
     const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
@@ -450,24 +520,25 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
     RCCHK(launch_tail(e, s, t));
   }
+  e->node_role = (j & 1) ? "actor1/q(s,pi)" : "actor0/q(s,pi)";
   {  // Q_i(s, a_pi) through the online critics as constants (agent.py:272-278)
     const TrunkGrp g{e->Xp, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1};
     TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
     if (e->alpha_pending) { tk.alpha = &e->pending_alpha; e->alpha_pending = false; }   // the previous update's temperature step
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, tk));
   }
+  e->node_role = (j & 1) ? "actor1/loss+backward" : "actor0/loss+backward";
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_sa;
-    hipLaunchKernelGGL(k_actorq_tail<4>, dim3(e->nblk4), dim3(64), 0, s, t);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_actorq_tail<4>", 2.0 * nq * B * (double)HID, 4.0 * nq * (2.0 * BH + 4.0 * HID + 2.0 * B), k_actorq_tail<4>, dim3(e->nblk4), dim3(64), t);
   }
   {
     NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
-    RCCHK(launch_nn(e, s, g, nq));
+    RCCHK(launch_nn(e, s, "k_nn.dh1", g, nq));
   }
   {
     LnBwd l{};
@@ -476,8 +547,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     l.dz = e->c_dz1; l.part = e->part; l.pstride = e->nblk4;
     // fused: dA_i = dz1_i W1_i[:, o:o+a]  (gradient of Q_i with respect to the action)
     l.W1 = e->Pc + e->Lc.W1; l.ldw1 = e->Lc.ld1; l.k_off = e->o; l.na = e->a; l.dA = e->dA; l.ldA = e->a4;
-    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, nq), dim3(256), 0, s, l);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_ln_bwd<16>.dQ/da", 2.0 * nq * B * (double)HID * e->a, 4.0 * nq * (4.0 * BH + B + HID + (double)HID * e->a + (double)B * e->a),
+           k_ln_bwd<16>, dim3(e->nblk, nq), dim3(256), l);
   }
   {
     ActorHeadBwd h{};
@@ -485,20 +556,19 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.xh2 = e->a_xh2; h.rstd2 = e->a_rs2; h.h2 = e->a_h2;
     h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
     h.part = e->part;
-    hipLaunchKernelGGL(k_actor_head_bwd, dim3(e->nblk), dim3(256), 0, s, h);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_actor_head_bwd", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
+           k_actor_head_bwd, dim3(e->nblk), dim3(256), h);
   }
   {
     NnArgs g{};
     g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
-    RCCHK(launch_nn(e, s, g, 1));
+    RCCHK(launch_nn(e, s, "k_nn.dh1", g, 1));
   }
   {
     LnBwd l{};
     l.dh = e->a_dh1; l.xh = e->a_xh1; l.h = e->a_h1; l.rstd = e->a_rs1; l.gamma = e->Pa + e->La.g1;
     l.B = B; l.ln = ln; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.pstride = e->nblk4;
-    hipLaunchKernelGGL(k_ln_bwd<16>, dim3(e->nblk, 1), dim3(256), 0, s, l);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_ln_bwd<16>", 0.0, 4.0 * (4.0 * BH + B + HID), k_ln_bwd<16>, dim3(e->nblk, 1), dim3(256), l);
   }
   {  // every actor gradient (+ Adam unless clip_grad_norm_ needs the global norm first) in one launch:
      //   dWhead = du^T h2, dbhead ; dW2 = dz2^T h1, db2, dgamma2, dbeta2 ; dW1 = dz1^T s, db1, dgamma1, dbeta1
@@ -514,17 +584,17 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
     g.loss_part = e->part_sa; g.loss_n = e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
     g.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS]; g.tick = (td3 && !clip) ? &e->ctl->noise_ctr : nullptr;
-    RCCHK(launch_tn(e, s, g, 1));
+    RCCHK(launch_tn(e, s, clip ? "dW" : "dW+adam", g, 1));
   }
   if (clip) {
     NormArgs n{e->Ga, (long)e->La.size, c.clip_norm, e->gscale};
-    hipLaunchKernelGGL(k_gradnorm, dim3(1), dim3(1024), 0, s, n);
-    HIPCHK(hipGetLastError());
+    LAUNCH("k_gradnorm", 0.0, 4.0 * e->La.size, k_gradnorm, dim3(1), dim3(1024), n);
     AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, e->ctl->adam_a);
     a.gscale = e->gscale;
     a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_adam(e, s, a));
   }
+  e->node_role = (j & 1) ? "actor1/alpha" : "actor0/alpha";
   if (!td3) {
     if (c.autotune && merge_next) {
       // The temperature draw (agent.py:297-299) and the next actor update's policy sample (agent.py:254) both go through
@@ -549,8 +619,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     al.lr = c.log_alpha_lr; al.b1 = c.adam_beta1; al.b2 = c.adam_beta2; al.eps = c.adam_eps; al.tick = &e->ctl->noise_ctr;
     if (merge_next) { e->pending_alpha = al; e->alpha_pending = true; }   // rides in the next update's critic-trunk launch
     else {
-      hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, s, al);
-      HIPCHK(hipGetLastError());
+      LAUNCH("k_alpha_step", 0.0, 4.0 * B, k_alpha_step, dim3(1), dim3(256), al);
     }
   }
   return 0;
@@ -558,20 +627,21 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
 
 // agents/agent.py:328-331
 static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool actor) {
+  e->node_role = "targets";
   PolyakArgs p{};
   p.tau = e->cfg.polyak;
   if (critics) { p.t0 = e->Tc; p.p0 = e->Pc; p.n0 = 2L * e->Lc.size; }
   if (actor) { p.t1 = e->Ta; p.p1 = e->Pa; p.n1 = e->La.size; }
   const long n = p.n0 + p.n1;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_polyak, dim3((unsigned)std::min<long>(512, (n / 4 + 255) / 256)), dim3(256), 0, s, p);
-  HIPCHK(hipGetLastError());
+  LAUNCH("k_polyak", 0.0, 12.0 * n, k_polyak, dim3((unsigned)std::min<long>(512, (n / 4 + 255) / 256)), dim3(256), p);
   return 0;
 }
 
 // orchestrator.py:337-352 as one sequence
 static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
+  e->node_role = "sample";
   if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
@@ -642,6 +712,7 @@ const char* sactd3_last_error(const sactd3_engine* e) { return e ? e->err.c_str(
 
 void sactd3_destroy(sactd3_engine* e) {
   if (!e) return;
+  (void)hipSetDevice(e->cfg.device_id);
   if (e->stream) hipStreamSynchronize(e->stream);
   for (auto& g : e->graphs) if (g) hipGraphExecDestroy(g);
   for (auto ev : e->events) hipEventDestroy(ev);
@@ -667,6 +738,10 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SACTD3_ALLOW_ANY_ARCH"))
     return e->fail(SACTD3_ENODEV, "device is not gfx950 (this library carries gfx950 code objects only)");
   e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // tuning aids: read once here, never on a launch path
+  if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
+  if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
+  if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) e->tune_tn_kt = v; }
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
   e->o = c.ob_dim; e->a = c.ac_dim; e->B = c.batch_size;
@@ -803,6 +878,7 @@ static int write_arena(sactd3_engine* e, float* dev, const NetLayout& L, int net
 
 int sactd3_get_params(sactd3_engine* e, int which, float* dst) {
   if (!e || !dst) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (which == SACTD3_LOG_ALPHA) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(dst, e->la, sizeof(float), hipMemcpyDeviceToHost));
@@ -815,6 +891,7 @@ int sactd3_get_params(sactd3_engine* e, int which, float* dst) {
 
 int sactd3_set_params(sactd3_engine* e, int which, const float* src) {
   if (!e || !src) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (which == SACTD3_LOG_ALPHA) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->la, src, sizeof(float), hipMemcpyHostToDevice));
@@ -827,6 +904,7 @@ int sactd3_set_params(sactd3_engine* e, int which, const float* src) {
 
 int sactd3_get_adam_state(sactd3_engine* e, int which, float* m, float* v, int64_t* step) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   DevCtl hc;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(&hc, e->ctl, sizeof(hc), hipMemcpyDeviceToHost));
@@ -849,6 +927,7 @@ int sactd3_get_adam_state(sactd3_engine* e, int which, float* m, float* v, int64
 
 int sactd3_set_adam_state(sactd3_engine* e, int which, const float* m, const float* v, int64_t step) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   const int st = (int)step;
   if (which == SACTD3_LOG_ALPHA) {
@@ -882,6 +961,7 @@ static void pack_record(const sactd3_engine* e, float* rec, const float* ob, con
 
 int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
   if (!e || !obs || !act || !rew || !nobs || !dones || n < 0) return e ? e->fail(SACTD3_EINVAL, "rb_extend: bad argument") : SACTD3_EINVAL;
+  USE_DEVICE(e);
   const int64_t cap = e->cfg.rb_capacity;
   int done_rows = 0;
   while (done_rows < n) {
@@ -914,6 +994,7 @@ int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EI
 
 int sactd3_rb_sample(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "rb_sample: buffer is empty");
   RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->sample_ctr, (int*)nullptr);
@@ -923,6 +1004,7 @@ int sactd3_rb_sample(sactd3_engine* e) {
 
 int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
   if (!e || !idx) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (n != e->B) return e->fail(SACTD3_EINVAL, "rb_sample_with_indices: n must equal batch_size");
   std::vector<int> h(n);
   for (int i = 0; i < n; ++i) {
@@ -938,6 +1020,7 @@ int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
 
 int sactd3_load_batch(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
   if (!e || !obs || !act || !rew || !nobs || !dones) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (n != e->B) return e->fail(SACTD3_EINVAL, "load_batch: n must equal batch_size");
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<int> h(n);
@@ -954,6 +1037,7 @@ int sactd3_load_batch(sactd3_engine* e, const float* obs, const float* act, cons
 
 int sactd3_read_batch(sactd3_engine* e, float* obs, float* act, float* rew, float* nobs, uint8_t* dones, int64_t* idx) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   const int B = e->B;
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<float> hx((size_t)B * e->ldc), hn((size_t)B * e->ldc), hr(B), hd(B);
@@ -976,6 +1060,7 @@ int sactd3_read_batch(sactd3_engine* e, float* obs, float* act, float* rew, floa
 
 int sactd3_rb_fill_synthetic(sactd3_engine* e, int64_t n, uint64_t seed) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (n < 1 || n > e->cfg.rb_capacity) return e->fail(SACTD3_EINVAL, "rb_fill_synthetic: 1 <= n <= rb_capacity");
   FillArgs f{(float4*)e->ring, e->rec4, e->cx, e->cn, e->o, e->a, (long)n, seed, e->min_ac, e->max_ac};
   const long threads = (long)n * e->rec4;
@@ -989,6 +1074,7 @@ int sactd3_rb_fill_synthetic(sactd3_engine* e, int64_t n, uint64_t seed) {
 // ---- noise
 int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
   if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (n < 1 || n > std::max(e->B, e->maxn)) return e->fail(SACTD3_EINVAL, "set_noise: too many rows");
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->eps[site], eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
@@ -998,6 +1084,7 @@ int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
 }
 int sactd3_clear_noise(sactd3_engine* e, int site) {
   if (!e || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   const int zeros[8] = {0};
   if (site < 0) HIPCHK(hipMemcpy(&e->ctl->inject_eps[0], zeros, sizeof(int) * 8, hipMemcpyHostToDevice));
@@ -1006,6 +1093,7 @@ int sactd3_clear_noise(sactd3_engine* e, int site) {
 }
 int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
   if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES || n < 1 || n > std::max(e->B, e->maxn)) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(eps, e->eps[site], sizeof(float) * (size_t)n * e->a, hipMemcpyDeviceToHost));
   return 0;
@@ -1014,20 +1102,24 @@ int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
 // ---- updates
 int sactd3_update_qnets(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   return run_graph(e, G_Q, [&](hipStream_t s) { return enqueue_update_qnets(e, s, false, nullptr); });
 }
 int sactd3_update_actor(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   return run_graph(e, G_A, [&](hipStream_t s) { return enqueue_update_actor(e, s, 0); });
 }
 int sactd3_update_targ_nets(sactd3_engine* e, int64_t qnet_updates_so_far) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   const bool td3 = e->cfg.prefer_td3_over_sac;
   if (td3 || qnet_updates_so_far % e->cfg.crit_targ_update_freq == 0) return enqueue_polyak(e, e->stream, true, td3);
   return 0;
 }
 int sactd3_step(sactd3_engine* e, int do_actor) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step: buffer is empty");
   e->qnet_updates += 1;
   const bool polyak = e->cfg.prefer_td3_over_sac || (e->qnet_updates % e->cfg.crit_targ_update_freq == 0);
@@ -1038,6 +1130,7 @@ int sactd3_step(sactd3_engine* e, int do_actor) {
 
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions) {
   if (!e || !obs || !actions) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (n < 1 || n > e->maxn) return e->fail(SACTD3_EINVAL, "predict: 1 <= n <= max_envs");
   const bool td3 = e->cfg.prefer_td3_over_sac;
   HIPCHK(hipStreamSynchronize(e->stream));   // pinned staging is reused
@@ -1069,6 +1162,7 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
 
 int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]) {
   if (!e || !out) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, e->ctl->metrics, sizeof(float) * SACTD3_NUM_METRICS, hipMemcpyDeviceToHost));
   return 0;
@@ -1076,6 +1170,7 @@ int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]) {
 
 int sactd3_sync(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
@@ -1100,6 +1195,7 @@ const char* sactd3_debug_names(void) {
 }
 int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_t max_floats) {
   if (!e || !name) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (!strcmp(name, "grad_actor") || !strcmp(name, "grad_critics")) {   // reference (unpadded) layout
     const bool act = !strcmp(name, "grad_actor");
     const int64_t n = sactd3_param_count(e, act ? SACTD3_ACTOR : SACTD3_CRITICS);
@@ -1130,11 +1226,17 @@ int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
 
 int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec) {
   if (!e || !kernel || !usec || iters < 1) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   hipEvent_t t0, t1;
   HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
   int rc = 0;
   auto body = [&]() -> int {
-    if (!strcmp(kernel, "gather")) return enqueue_gather(e, e->stream, e->ring, -1);
+    if (!strcmp(kernel, "gather")) {   // a fresh index draw per launch (k_tick bumps the sample counter): rows come from HBM, not from the caches
+      RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
+      hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->sample_ctr, (int*)nullptr);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     if (!strcmp(kernel, "polyak")) return enqueue_polyak(e, e->stream, true, e->cfg.prefer_td3_over_sac);
     if (!strcmp(kernel, "trunk_critics")) {   // the 4-net hidden-layer launch of update_qnets (no state is modified)
       const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
@@ -1157,8 +1259,54 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
   return rc;
 }
 
+// Per-node device time of one fused iteration.  The enqueue sequence of sactd3_step(do_actor) is walked once to list
+// its kernel launches (node registry), then each launch alone is issued `iters` times back to back between two HIP
+// events on the engine's stream (the other launches of the sequence are skipped).  The learner's state is consumed by
+// this (optimiser steps repeat on stale gradients): use a scratch engine.
+int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, char* names, int names_cap,
+                      float* usec, double* flops, double* bytes, int64_t* threads) {
+  if (!e || iters < 1 || max_nodes < 1 || !usec) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "time_nodes: buffer is empty");
+  const bool act = do_actor != 0 && e->cfg.actor_update_delay > 0;
+  std::vector<NodeInfo> log;
+  auto seq = [&]() -> int { e->node_seq = 0; return enqueue_step(e, e->stream, act, true); };
+  auto done = [&](int rc) { e->node_only = -1; e->node_log = nullptr; e->node_seq = 0; e->node_role = ""; return rc; };
+  e->node_log = &log; e->node_only = 1 << 30;               // list only, launch nothing
+  int rc = seq();
+  e->node_log = nullptr;
+  if (rc != 0) return done(rc);
+  const int n = (int)log.size();
+  if (n > max_nodes) return done(e->fail(SACTD3_EINVAL, "time_nodes: max_nodes too small"));
+  std::string joined;
+  for (int k = 0; k < n; ++k) { joined += log[k].name; joined += '\n'; }
+  if (names) {
+    if ((int)joined.size() + 1 > names_cap) return done(e->fail(SACTD3_EINVAL, "time_nodes: names buffer too small"));
+    memcpy(names, joined.c_str(), joined.size() + 1);
+  }
+  hipEvent_t t0, t1;
+  HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+  for (int k = 0; k < n && rc == 0; ++k) {
+    e->node_only = k;
+    for (int i = 0; i < 3 && rc == 0; ++i) rc = seq();
+    hipEventRecord(t0, e->stream);
+    for (int i = 0; i < iters && rc == 0; ++i) rc = seq();
+    hipEventRecord(t1, e->stream);
+    if (hipEventSynchronize(t1) != hipSuccess) rc = e->fail(SACTD3_EHIP, "time_nodes: hipEventSynchronize");
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t0, t1);
+    usec[k] = ms * 1000.f / (float)iters;
+    if (flops) flops[k] = log[k].flops;
+    if (bytes) bytes[k] = log[k].bytes;
+    if (threads) threads[k] = log[k].threads;
+  }
+  hipEventDestroy(t0); hipEventDestroy(t1);
+  return done(rc == 0 ? n : rc);
+}
+
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes) {
   if (!e || !usec || batch < 1 || iters < 1) return SACTD3_EINVAL;
+  USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "gather sweep: buffer is empty");
   if ((long long)batch * e->rec4 >= (1ll << 31)) return e->fail(SACTD3_EINVAL, "gather sweep: batch too large");
   float *X = nullptr, *Xn = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;

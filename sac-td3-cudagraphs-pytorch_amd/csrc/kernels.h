@@ -1090,15 +1090,17 @@ struct ActorTail {
 
 // the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
 // (only for output elements beyond a thread's first, i.e. ac_dim > 16: the first one is handled branch-free in the kernel)
-__device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr_add,
+// `ctr` is the stream counter the kernel read at its start: block 0 may bump the counter word at its end (p.tick), so it
+// must not be read from memory a second time
+__device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr,
                                            int bc, int b, int j, bool valid) {
   if (p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
-  const float e = philox_normal(p.ctl->seed, (unsigned)(*p.ctr + ctr_add), site_code, (unsigned)(bc * p.a + j));
+  const float e = philox_normal(p.ctl->seed, (unsigned)ctr, site_code, (unsigned)(bc * p.a + j));
   if (valid) eps[(long)b * p.a + j] = e;
   return e;
 }
-__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int bc, int b, int j, bool valid) {
-  return need_eps ? tail_draw(p, p.site_buf, p.site_code, p.eps, p.ctr_add, bc, b, j, valid) : 0.f;
+__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int ctr, int bc, int b, int j, bool valid) {
+  return need_eps ? tail_draw(p, p.site_buf, p.site_code, p.eps, ctr + p.ctr_add, bc, b, j, valid) : 0.f;
 }
 
 // Memory discipline of this kernel (and of every kernel here): ALL global loads of the common case go out first, behind
@@ -1269,8 +1271,8 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   };
   if (sub < p.a) element(sub, e_bh0, e_bh1, e_sc, e_bi, e_lo, e_hi, e_eps, e_eps2);       // operands already in registers
   for (int j = sub + 16; j < p.a; j += 16) {                                   // ac_dim > 16 only
-    const float e = tail_noise(p, need_eps, bc, b, j, valid);
-    const float e2 = p.dual ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, 0, bc, b, j, valid) : 0.f;
+    const float e = tail_noise(p, need_eps, ctr, bc, b, j, valid);
+    const float e2 = p.dual ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, ctr, bc, b, j, valid) : 0.f;
     element(j, p.P[p.L.bh + j], p.sac ? p.P[p.L.bh + p.a + j] : 0.f, p.scale[j], p.bias[j], smooth ? p.min_ac[j] : 0.f, smooth ? p.max_ac[j] : 0.f, e, e2);
   }
   STAMP(4);

@@ -76,7 +76,8 @@ class Config:
                   "seed"):
             setattr(c, k, type(getattr(c, k))(get(k, getattr(c, k))))
         c.max_envs = max(int(get("num_envs", 4)), 1)
-        c.use_graphs = bool(get("cudagraphs", True))
+        # NOT hps.cudagraphs: INTEGRATION.md runs the reference loop with `cudagraphs: false` so that orchestrator.py:313-315
+        # does not wrap these methods in CudaGraphModule; the engine's own hipGraphs stay on unless `use_graphs=False` is passed
         for k, v in over.items():
             setattr(c, k, v)
         return c
@@ -146,6 +147,9 @@ class Engine:
 
     def set_adam_state(self, which: int, m, v, step: int) -> None:
         m, v = _f32(m).reshape(-1), _f32(v).reshape(-1)
+        n = self.param_count(which)
+        if m.size != n or v.size != n:
+            raise ValueError(f"expected {n} floats of exp_avg / exp_avg_sq, got {m.size} / {v.size}")
         self._ck(self.lib.sactd3_set_adam_state(self._h, which, _fp(m), _fp(v), int(step)))
 
     # -- replay
@@ -171,6 +175,8 @@ class Engine:
 
     def rb_sample_with_indices(self, idx) -> None:
         idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64).reshape(-1))
+        if idx.size != self.cfg.batch_size:
+            raise ValueError(f"expected {self.cfg.batch_size} indices, got {idx.size}")
         self._ck(self.lib.sactd3_rb_sample_with_indices(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size))
 
     def load_batch(self, obs, act, rew, nobs, done) -> None:
@@ -247,6 +253,17 @@ class Engine:
         us = C.c_float(0)
         self._ck(self.lib.sactd3_time_kernel(self._h, name.encode(), iters, C.byref(us)))
         return float(us.value)
+
+    def time_nodes(self, do_actor: bool, iters: int = 200):
+        """[{name, us, flops, bytes}] for every kernel node of one fused iteration (consumes the learner's state)."""
+        cap = 128
+        us, fl, by, th = np.zeros(cap, np.float32), np.zeros(cap, np.float64), np.zeros(cap, np.float64), np.zeros(cap, np.int64)
+        names = C.create_string_buffer(cap * 128)
+        dp = C.POINTER(C.c_double)
+        n = self._ck(self.lib.sactd3_time_nodes(self._h, int(bool(do_actor)), iters, cap, names, len(names), _fp(us),
+                                                fl.ctypes.data_as(dp), by.ctypes.data_as(dp), th.ctypes.data_as(C.POINTER(C.c_int64))))
+        labels = names.value.decode().split("\n")[:n]
+        return [dict(name=labels[k], us=float(us[k]), flops=float(fl[k]), bytes=float(by[k]), threads=int(th[k])) for k in range(n)]
 
     def time_gather_sweep(self, batch: int, iters: int = 50):
         us, nbytes = C.c_float(0), C.c_double(0)

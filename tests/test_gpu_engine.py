@@ -32,13 +32,13 @@ def gclose(got, want, name=""):
     close(got, want, rtol=2e-4, atol=2e-6 + 1e-5 * float(np.abs(want).max()), name=name)
 
 
-def make_pair(algo, env, B, ln=True, seed=0, use_graphs=True, **hp):
+def make_pair(algo, env, B, ln=True, seed=0, use_graphs=True, rb_capacity=4096, **hp):
     o, a, bound = DIMS[env]
     hps = (Hps.td3 if algo == "td3" else Hps.sac)(layer_norm=ln, batch_size=B, **hp)
     torch.manual_seed(seed)
     ref = RefAgent(o, a, [-bound] * a, [bound] * a, hps)
     randomize_ln(ref)
-    cfg = P.Config.from_hps(hps, o, a, rb_capacity=4096, max_envs=8, seed=seed, use_graphs=use_graphs)
+    cfg = P.Config.from_hps(hps, o, a, rb_capacity=rb_capacity, max_envs=8, seed=seed, use_graphs=use_graphs)
     eng = P.Engine(cfg, [-bound] * a, [bound] * a)
     push_params(eng, ref)
     return ref, eng, (o, a, bound)
@@ -378,14 +378,69 @@ def test_graph_replay_equals_eager_launches(algo, env):
     assert outs[0][4] > 0 and outs[1][4] == 0
 
 
-@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah"), ("sac", "humanoid")])
-def test_fused_step_equals_api_sequence(algo, env):
-    """sactd3_step (one graph per iteration) == rb_sample + update_qnets + 2x update_actor + update_targ_nets."""
-    B = 64
+BASELINE_SHAPES = [("sac", "hopper", 256, 100_000), ("td3", "halfcheetah", 256, 100_000), ("sac", "humanoid", 1024, 65_536)]
+
+
+@pytest.mark.parametrize("algo,env,B,cap", BASELINE_SHAPES)
+def test_fused_step_against_oracle_at_baseline_shapes(algo, env, B, cap):
+    """The TIMED path (sactd3_step: one hipGraph per iteration, native Philox sampling and noise) against the oracle at
+    BASELINE.json's shapes -- configs 2 / 3 / 4: SAC Hopper B=256, TD3 HalfCheetah B=256, SAC Humanoid B=1024 with a
+    65 536-row ring.  After every fused iteration the batch indices the engine drew and the normals it used at every
+    noise site are read back and the oracle's `iteration` (orchestrator.py:337-352) is driven with exactly those, in the
+    reference's draw order critic -> [actor -> alpha] x delay (agents/agent.py:205,254,298).  This exercises what only
+    the fused form runs: the ring-indirect first layer, the gather blocks riding in the first trunk launch, the dual-draw
+    actor tail, the temperature step riding in the next trunk launch, and at B >= 1024 the k_gather + k_nt64 route.
+    Tolerance: losses / alpha rtol 1e-5 + atol 1e-5 on the first iteration (north_star), widening with the iteration
+    number as in test_trajectory_api_path; parameters: tests/helpers.py:assert_params_close."""
+    ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=5, rb_capacity=cap)
+    n = min(cap, 65_536)
+    rows = [t.numpy() for t in synth_transitions(n, o, a, bound, seed=61)]
+    rows[4][::9] = True
+    for lo in range(0, n, 8192):
+        eng.rb_extend(*[r[lo:lo + 8192] for r in rows])
+    assert eng.rb_len() == n
+    delay, n_iter = ref.hps.actor_update_delay, 7
+    sites_a, sites_l = (_lib.SITE_ACTOR0, _lib.SITE_ACTOR1), (_lib.SITE_ALPHA0, _lib.SITE_ALPHA1)
+    for i in range(n_iter):
+        do_actor = i % (delay + 1) == 0
+        eng.step(do_actor)
+        got_b = eng.read_batch()
+        idx = got_b["index"]
+        assert idx.min() >= 0 and idx.max() < n
+        for k, r in zip(("observations", "actions", "rewards", "next_observations", "dones"), rows):
+            assert np.array_equal(got_b[k], r[idx]), (i, k)                       # the gather itself: bit-exact
+        noise = {"critic": torch.from_numpy(eng.read_noise(_lib.SITE_CRITIC))}
+        if do_actor and algo == "sac":
+            noise["actor"] = [torch.from_numpy(eng.read_noise(sites_a[j])) for j in range(delay)]
+            noise["alpha"] = [torch.from_numpy(eng.read_noise(sites_l[j])) for j in range(delay)]
+        b = ref.to_batch(*[r[idx] for r in rows])
+        want = {k: float(v) for k, v in ref.iteration(b, i, noise).items()}
+        got = eng.read_metrics()
+        tol = 1e-5 * (1 + 3 * i)
+        for k, v in want.items():
+            np.testing.assert_allclose(got[k], v, rtol=tol, atol=tol, err_msg=f"iter {i} {k}")
+    n_act = delay * len([i for i in range(n_iter) if i % (delay + 1) == 0])
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, n_iter, "critics", max_bad_frac=2e-2)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, n_act, "actor", max_bad_frac=2e-2)
+    assert_params_close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), ref.hps.qnets_lr, n_iter, "critic targets")
+    if algo == "td3":
+        assert_params_close(eng.get_params(_lib.ACTOR_TARGET), flat_actor(ref, ref.actor_target), ref.hps.actor_lr, n_act, "actor target")
+    else:
+        close(eng.get_params(_lib.LOG_ALPHA)[0], ref.log_alpha, rtol=1e-5, atol=1e-6, name="log_alpha")
+    _, _, tq = eng.get_adam_state(_lib.CRITICS)
+    _, _, ta = eng.get_adam_state(_lib.ACTOR)
+    assert tq == n_iter and ta == n_act                                          # counters of orchestrator.py:342,349
+
+
+@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 64), ("td3", "halfcheetah", 64), ("sac", "humanoid", 64),
+                                        ("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024)])
+def test_fused_step_equals_api_sequence(algo, env, B):
+    """sactd3_step (one graph per iteration) == rb_sample + update_qnets + 2x update_actor + update_targ_nets, bit for
+    bit, at a small batch and at BASELINE.json's batch sizes (where other kernel instances are chosen)."""
     res = []
     for fused in (True, False):
         ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=3)
-        obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(500, o, a, bound, seed=22)]
+        obs, act, rew, nobs, done = [t.numpy() for t in synth_transitions(3000, o, a, bound, seed=22)]
         eng.rb_extend(obs, act, rew, nobs, done)
         for i in range(7):
             if fused:
@@ -487,6 +542,63 @@ def test_agent_mirror_drives_like_the_reference():
     assert set(vals) == {"loss/qf_loss", "loss/actor_loss", "loss/alpha_loss", "vitals/alpha"}
     assert all(np.isfinite(v) for v in vals.values())
     assert batch["observations"].shape == (64, o) and batch["dones"].shape == (64, 1)
+
+
+def test_engine_graphs_do_not_follow_the_reference_loops_cudagraphs_key():
+    """INTEGRATION.md runs the reference loop with `cudagraphs: false` (so that orchestrator.py:313-315 does not wrap the
+    ctypes-backed methods in CudaGraphModule); the engine's own hipGraphs stay on, and can be switched off explicitly."""
+    from types import SimpleNamespace
+    o, a, bound = DIMS["hopper"]
+    mk = lambda **kw: P.Agent({"ob_shape": (o,), "ac_shape": (a,)}, np.full(a, -bound, np.float32), np.full(a, bound, np.float32), torch.device("cuda:0"),
+                              SimpleNamespace(**{**Hps.sac(batch_size=32).__dict__, "cudagraphs": False, "rb_capacity": 256, "seed": 0}),
+                              P.ReplayBuffer(256), **kw)
+    for kw, want in ((dict(), True), (dict(use_graphs=True), True), (dict(use_graphs=False), False)):
+        ag = mk(**kw)
+        ag.engine.rb_fill_synthetic(200)
+        ag.iteration(0)
+        ag.update_qnets(ag.rb.sample(32))
+        ag.engine.sync()
+        assert (ag.engine.graph_kernel_count(0) > 0) == want and (ag.engine.graph_kernel_count(3) > 0) == want
+
+
+def test_calls_run_on_the_engines_device_whatever_the_current_device_is():
+    """every ABI entry point selects the engine's device itself (a caller thread that changed its current device, or a
+    fresh thread, must not break a call): drive an engine from a second Python thread."""
+    import threading
+    ref, eng, (o, a, bound) = make_pair("sac", "hopper", 32)
+    eng.rb_fill_synthetic(500)
+    res = {}
+
+    def work():
+        try:
+            for i in range(4):
+                eng.step(i % 3 == 0)
+            res["m"] = eng.read_metrics()
+            res["act"] = eng.predict(np.zeros((2, o), np.float32), explore=False)
+        except Exception as ex:            # noqa: BLE001
+            res["err"] = ex
+    th = threading.Thread(target=work)
+    th.start(); th.join()
+    assert "err" not in res, res.get("err")
+    assert all(np.isfinite(v) for v in res["m"].values()) and res["act"].shape == (2, a)
+
+
+def test_time_nodes_lists_the_iteration_graphs():
+    """sactd3_time_nodes walks the same enqueue sequence the graphs are captured from: node counts agree with the
+    instantiated graphs (7 / 30 at Hopper shapes) and every node has a kernel-instance name, a grid and a time."""
+    ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256)
+    eng.rb_fill_synthetic(2000)
+    for i in range(3):
+        eng.step(i % 3 == 0)
+    eng.sync()
+    n0, n1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
+    g0, g1 = eng.time_nodes(False, 5), eng.time_nodes(True, 5)
+    assert (len(g0), len(g1)) == (n0, n1) == (7, 30)
+    for n in g0 + g1:
+        assert n["name"].startswith("k_") and ":" in n["name"] and n["threads"] > 0 and 0.0 < n["us"] < 1e4
+    assert sum(n["flops"] for n in g0) > 0.3e9      # (critic update of SURVEY 8d: A + 8C per sample at B = 256)
+    eng.step(False)                                 # the engine still runs afterwards
+    assert all(np.isfinite(v) for v in eng.read_metrics().values())
 
 
 # ------------------------------------------------------------------------------------------ config corners

@@ -1,8 +1,11 @@
 """CPU, world_size 2 over gloo: the seed-parallel launcher's sharding, barrier and timing aggregation (the N > 1
 path of bench.py).  Replicas only: no tensor of the learners ever crosses ranks."""
+import json
 import os
 import pytest
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.multiprocessing as mp
@@ -95,3 +98,20 @@ def test_sweep_enumeration_and_gpu_assignment():
     assert launcher.shard_jobs(launcher.sweep_jobs("debug", 8), 8, 5) == [("Hopper-v4", 5)]      # the 8-seed node of BASELINE.json
     with pytest.raises(ValueError):
         launcher.sweep_jobs("nope", 1)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` WITHOUT a torch.distributed.run environment (the form the driver uses for SCALE runs)
+    must come back as ONE line with n_gpus == 2: the parent starts the ranks as fresh children before anything touches a
+    GPU (the reference's counterpart: one OS process per seed, spawner.py:291,313-349).  Here without a GPU: --dry-run-ranks
+    replaces the learner by a no-op, everything else (launch, gloo rendezvous, barrier, max-over-ranks, JSON) is real."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "2", "--dry-run-ranks"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["dry_run"] is True and d["value"] is None
+    assert d["config"]["parallelism"].startswith("2 independent seeds")
