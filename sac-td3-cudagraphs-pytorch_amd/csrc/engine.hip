@@ -109,6 +109,7 @@ struct sactd3_engine {
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
   float* s_h1 = nullptr;         // large-batch path: layer-1 activations of nets whose caller keeps no copy ([4][B][256])
+  float* Gp = nullptr; int gp_slabs = 0;      // large-batch path: split-M partial slabs of the weight gradients ([slab][nets][arena])
   float *part = nullptr, *part_s = nullptr, *part_sa = nullptr;   // column partials; scalar partials of the critic / actor updates
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
   float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
@@ -118,7 +119,7 @@ struct sactd3_engine {
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
-  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0;
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
   // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
@@ -143,6 +144,7 @@ struct sactd3_engine {
   do {                                                                                       \
     hipError_t _he = hipSetDevice((e)->cfg.device_id);                                       \
     if (_he != hipSuccess) return (e)->fail(SACTD3_EHIP, "hipSetDevice", _he);               \
+    (void)hipGetLastError();   /* a stale error of an unrelated earlier call must not be blamed on this one */ \
   } while (0)
 #define RCCHK(call)                    \
   do {                                 \
@@ -187,13 +189,14 @@ static inline bool node_on(sactd3_engine* e, const char* name, double flops, dou
   }
   return e->node_only < 0 || e->node_only == k;
 }
-#define LAUNCH(name, flops, bytes, kernel, grid, block, ...)                \
+#define LAUNCH_DYN(name, flops, bytes, kernel, grid, block, dyn_lds, ...)    \
   do {                                                                      \
     if (node_on(e, name, flops, bytes, grid, block)) {                      \
-      hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);           \
+      hipLaunchKernelGGL(kernel, grid, block, dyn_lds, s, __VA_ARGS__);     \
       HIPCHK(hipGetLastError());                                            \
     }                                                                       \
   } while (0)
+#define LAUNCH(name, flops, bytes, kernel, grid, block, ...) LAUNCH_DYN(name, flops, bytes, kernel, grid, block, 0, __VA_ARGS__)
 
 static inline dim3 tile_grid(int tiles, int nets) { return dim3((unsigned)((tiles + 3) / 4), 1, (unsigned)nets); }
 
@@ -278,7 +281,61 @@ static int launch_nn(sactd3_engine* e, hipStream_t s, const char* name, const Nn
          k_nn, grid, dim3(256), g);
   return 0;
 }
+// block tile / chunk rows of the large-batch weight-gradient GEMM (must agree with the k_tn64 instance launched)
+#ifndef TN64_CFG
+#define TN64_CFG 2, 2, 2, 1, 64      /* 64 (n) x 32 (k) tile, 64-row chunks: the fastest of tools/kprobe_tn64.hip's shapes */
+#define TN64_N 64
+#define TN64_K 32
+#define TN64_M 64
+#endif
+#define TN64_KERNEL (k_tn64<TN64_CFG>)
+// Large batches: split-M GEMM into partial slabs (k_tn64) + slab sum / vector gradients / Adam / Polyak (k_adam_red).
+static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const TnArgs& g, int nets) {
+  Tn64Args a{};
+  a.nprob = g.nprob; a.M = g.M; a.nets = nets; a.Gp = e->Gp; a.g_ns = nets > 1 ? g.g_ns : (long)e->La.size;
+  AdamRedArgs r{};
+  r.s_off = -1;
+  int tiles = 0;
+  double fl = 0.0, by = 0.0;
+  for (int i = 0; i < g.nprob; ++i) {
+    const TnProb& q = g.pr[i];
+    Tn64Prob& t = a.pr[i];
+    t.dY = q.dY; t.ldy = q.ldy; t.dy_ns = q.dy_ns; t.N = q.N; t.X = q.X; t.ldx = q.ldx; t.x_ns = q.x_ns; t.K = q.K;
+    t.w_off = q.w_off; t.ldw = q.ldw; t.b_off = q.b_off;
+    t.tiles_n = (q.N + TN64_N - 1) / TN64_N; t.tiles_k = (q.ldw + TN64_K - 1) / TN64_K; t.tile0 = tiles;
+    tiles += t.tiles_n * t.tiles_k;
+    for (int f = 0; f < q.nfin; ++f) { r.vec[r.nvec].off = q.fin_off[f]; r.vec[r.nvec].slot = q.fin_slot[f]; ++r.nvec; r.vec_nblk = q.fin_nblk[f]; }
+    if (q.fin_s_off >= 0) { r.s_off = q.fin_s_off; r.s_nblk = q.fin_s_nblk; }
+    fl += 2.0 * nets * (double)g.M * q.N * q.K;
+    by += 4.0 * nets * (double)g.M * (q.N + q.K);
+  }
+  a.tiles_per_net = tiles;
+  const int nch = (g.M + TN64_M - 1) / TN64_M;
+  // slices: about two blocks per CU, all of (nearly) the same length
+  int S = (2 * e->num_cus + tiles * nets / 2) / (tiles * nets);
+  S = std::max(1, std::min(S, std::min(e->gp_slabs, nch)));
+  a.S = S;
+  const long size = a.g_ns;
+  {
+    const dim3 grid((unsigned)(tiles * nets * S));
+    char inst[96];
+    snprintf(inst, sizeof(inst), "k_tn64.dW(split-M x%d)", S);
+    LAUNCH(inst, fl, by + 4.0 * S * nets * (double)size, TN64_KERNEL, grid, dim3(256), a);
+  }
+  r.Gp = e->Gp; r.S = S; r.nets = nets; r.g_ns = size; r.G = g.G;
+  r.apply = g.apply; r.P = g.P; r.Mo = g.Mo; r.Vo = g.Vo; r.T = g.T; r.tau = g.tau; r.adam = g.adam; r.b1 = g.b1; r.b2 = g.b2; r.eps = g.eps;
+  r.part = g.part; r.pstride = g.pstride; r.part_s = g.part_s;
+  r.loss_part = g.loss_part; r.loss_n = g.loss_n; r.loss_stride = g.loss_stride; r.loss_off = g.loss_off; r.loss_scale = g.loss_scale;
+  r.loss_dst = g.loss_dst; r.tick = g.tick;
+  const dim3 grid((unsigned)((size / 4 + 255) / 256 + 4 * r.nvec + 1), (unsigned)nets);
+  LAUNCH(g.apply ? (g.T ? "k_adam_red.sum+adam+polyak" : "k_adam_red.sum+adam") : "k_adam_red.sum", 0.0,
+         nets * (double)size * (4.0 * S + 4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)), k_adam_red, grid, dim3(256), r);
+  (void)name;
+  return 0;
+}
+
 static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets) {
+  if (g.M >= BIG_BATCH && e->Gp && !e->tune_tn_kt) return launch_tn64(e, s, name, g, nets);
   auto count = [&](int kt) {
     int tiles = 0;
     for (int i = 0; i < g.nprob; ++i) {
@@ -345,8 +402,8 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
     const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64) * nets));
     const double by_w = 4.0 * nets * (double)HID, by_rows = 4.0 * nets * (double)M * HID;
-    LAUNCH("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
-           (k_nt64<4, 2, 2>), grid, dim3(512), g);
+    LAUNCH_DYN("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
+               (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, g);
     LnFwd l{};
     l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
     for (int i = 0; i < ngrp; ++i) {
@@ -363,7 +420,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
     h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
     for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
-    LAUNCH("k_nt64<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 1) + 2.0 * by_rows, (k_nt64<4, 2, 2>), grid, dim3(512), h2);
+    LAUNCH_DYN("k_nt64<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 1) + 2.0 * by_rows, (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, h2);
     return 0;
   }
   if (K <= 64) {
@@ -712,7 +769,7 @@ const char* sactd3_last_error(const sactd3_engine* e) { return e ? e->err.c_str(
 
 void sactd3_destroy(sactd3_engine* e) {
   if (!e) return;
-  (void)hipSetDevice(e->cfg.device_id);
+  if (e->stream) (void)hipSetDevice(e->cfg.device_id);   // (a failed create may carry a device_id that was never valid)
   if (e->stream) hipStreamSynchronize(e->stream);
   for (auto& g : e->graphs) if (g) hipGraphExecDestroy(g);
   for (auto ev : e->events) hipEventDestroy(ev);
@@ -741,6 +798,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   // tuning aids: read once here, never on a launch path
   if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
+  if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
   if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) e->tune_tn_kt = v; }
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
@@ -784,6 +842,10 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->q, 2 * B)); RCCHK(dalloc(e, &e->qt, 2 * B)); RCCHK(dalloc(e, &e->y, B)); RCCHK(dalloc(e, &e->q_pi, 2 * B));
   RCCHK(dalloc(e, &e->dA, 2 * B * e->a4));
   if (e->B >= BIG_BATCH) RCCHK(dalloc(e, &e->s_h1, 4 * BH));
+  if (e->B >= BIG_BATCH) {
+    e->gp_slabs = 8;
+    RCCHK(dalloc(e, &e->Gp, (size_t)e->gp_slabs * std::max<size_t>(2 * (size_t)e->Lc.size, e->La.size)));
+  }
   RCCHK(dalloc(e, &e->part, 2 * (size_t)e->nblk4 * NSLOT * HID)); RCCHK(dalloc(e, &e->part_s, 2 * (size_t)e->nblk4 * 2)); RCCHK(dalloc(e, &e->part_sa, (size_t)e->nblk4 * 2));
   RCCHK(dalloc(e, &e->p_x, (size_t)e->maxn * e->ldo)); RCCHK(dalloc(e, &e->p_z1, (size_t)e->maxn * HID));
   RCCHK(dalloc(e, &e->p_z2, (size_t)e->maxn * HID)); RCCHK(dalloc(e, &e->p_act, (size_t)e->maxn * e->a4));

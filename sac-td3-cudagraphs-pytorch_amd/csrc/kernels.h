@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "philox.h"
 
 #define HID 256
@@ -138,6 +139,19 @@ __device__ __forceinline__ float4 gate4(float4 v, float4 y) {  // v where y > 0 
 // the compiler wait for each load before it issues the next one, which serialises a whole operand fetch.
 __device__ __forceinline__ float4 ld4_cols(const float* row, int k, int K, int Kr, bool row_ok = true) {
   const float4 v = ld4(row + min(k, Kr - 4));
+  float4 o;
+  o.x = (row_ok && k < K) ? v.x : 0.f;
+  o.y = (row_ok && k + 1 < K) ? v.y : 0.f;
+  o.z = (row_ok && k + 2 < K) ? v.z : 0.f;
+  o.w = (row_ok && k + 3 < K) ? v.w : 0.f;
+  return o;
+}
+
+// The two halves of ld4_cols for software-pipelined loops: the load is issued a whole stage before its value is masked.
+// (ld4_cols' selects sit right behind the load, and the compiler then waits for the load THERE -- in k_nt64 / k_tn that put
+// every stage's global round trip in front of the stage's MFMAs instead of under them.)
+__device__ __forceinline__ float4 ld4_raw(const float* row, int k, int Kr) { return ld4(row + min(k, Kr - 4)); }
+__device__ __forceinline__ float4 mask4_cols(float4 v, int k, int K, bool row_ok = true) {
   float4 o;
   o.x = (row_ok && k < K) ? v.x : 0.f;
   o.y = (row_ok && k + 1 < K) ? v.y : 0.f;
@@ -733,26 +747,35 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
 #pragma unroll                                    // every store wait for the one before it
   for (int tt = 0; tt < TT; ++tt) bias[tt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 16 * TT * wn + 16 * tt + r, p.N - 1)] : 0.f;
   float4 ra[RA], rw[RW];
-  auto fetch = [&](int c) {
+  auto fetch = [&](int c) {                       // raw loads only: the values are first touched by park(), a stage later
     const int k = c * KC64 + sc;
 #pragma unroll
-    for (int u = 0; u < RA; ++u) ra[u] = ld4_cols(ap[u], k, p.K, Kr);
+    for (int u = 0; u < RA; ++u) ra[u] = ld4_raw(ap[u], k, Kr);
 #pragma unroll
-    for (int u = 0; u < RW; ++u) rw[u] = ld4_cols(wp[u], k, p.K, Kr);
+    for (int u = 0; u < RW; ++u) rw[u] = ld4_raw(wp[u], k, Kr);
   };
-  auto park = [&](int buf) {
+  auto park = [&](int buf, int c) {
+    const int k = c * KC64 + sc;
+    if ((c + 1) * KC64 <= p.K) {                  // (uniform) a full chunk: no masks -- VALU work competes with the f32 MFMAs
 #pragma unroll
-    for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, ra[u]);
+      for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, ra[u]);
 #pragma unroll
-    for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, rw[u]);
+      for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, rw[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(ra[u], k, p.K));
+#pragma unroll
+      for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(rw[u], k, p.K));
+    }
   };
   STAMP(0);
   fetch(0);
-  park(0);
+  park(0, 0);
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int buf = c & 1;
     if (c + 1 < nc) fetch(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     const float* ab = As[buf] + (16 * wm + r) * LS64 + 4 * kq;
     const float* wb = Ws[buf] + (16 * TT * wn + r) * LS64 + 4 * kq;
 #pragma unroll
@@ -771,7 +794,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[tt].w, acc[tt], 0, 0, 0);
     }
-    if (c + 1 < nc) park(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < nc) park(buf ^ 1, c + 1);
     __syncthreads();
   }
   STAMP(1);
@@ -934,14 +958,14 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
   float4 vy[4], vx[KT][4];
-  auto fetch = [&](int mb) {
+  auto fetch = [&](int mb) {                      // raw loads; masked when the slab is parked in LDS, a stage later (see ld4_raw)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u, row = i >> 2, c4 = i & 3, m = mb + row, n = n0 + 4 * c4, k = k0 + 4 * c4;
       const long mc = min(m, p.M - 1);
-      vy[u] = ld4_cols(dYn + mc * q.ldy, n, q.N, Nr, m < p.M);
+      vy[u] = ld4_raw(dYn + mc * q.ldy, n, Nr);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) vx[kt][u] = ld4_cols(Xn + mc * q.ldx, k + 16 * kt, q.K, Kr, m < p.M);
+      for (int kt = 0; kt < KT; ++kt) vx[kt][u] = ld4_raw(Xn + mc * q.ldx, k + 16 * kt, Kr);
     }
   };
   fetch(0);
@@ -998,12 +1022,15 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     STAMP(1);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = t + 256 * u;
-      st4(Ys + (i >> 2) * YS + 4 * (i & 3), vy[u]);
+      const int i = t + 256 * u, c4 = i & 3;
+      const bool row_ok = mb + (i >> 2) < p.M;
+      st4(Ys + (i >> 2) * YS + 4 * c4, mask4_cols(vy[u], n0 + 4 * c4, q.N, row_ok));
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) st4(Xs + kt * 256 * YS + (i >> 2) * YS + 4 * (i & 3), vx[kt][u]);
+      for (int kt = 0; kt < KT; ++kt) st4(Xs + kt * 256 * YS + (i >> 2) * YS + 4 * c4, mask4_cols(vx[kt][u], k0 + 4 * c4 + 16 * kt, q.K, row_ok));
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (mb + 256 < p.M) fetch(mb + 256);                   // the next slab's rows fly under this slab's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                          // wave w: 16-row chunks w, w+4, w+8, w+12 of this slab
@@ -1063,6 +1090,320 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       if (lane == 0) *p.loss_dst = s * p.loss_scale;
     }
     if (lane == 0 && p.tick) *p.tick = tick_v + 1;
+  }
+}
+
+// ---- large-batch form of the weight gradients (M >= 1024).  k_tn's 16 x 16 tiles make every block re-read a [M][16]
+// column slice of both operands: at B = 1024 that is 168 MB of L2 -> CU traffic for 21 MB of operands (rocprofv3
+// FETCH_SIZE 81 MB: each XCD's L2 fills its own copy), and a block's 16 MFMAs per 256-row slab cannot cover the slab's
+// fetch + LDS transpose.  Here a block owns a (16 AN WN) x (16 AK WK) tile of dW over a SLICE of the batch rows (split-M):
+//   - operands stream as [TM rows][tile columns] chunks with whole-line loads, two chunks ahead of the MFMAs (register
+//     sets A / B), parked in a double-buffered LDS stage in their memory layout; the MFMA fragments are read as columns
+//     (4 ds_read_b32 per fragment, conflict-free with row strides = 4 mod 8): no transposed copies anywhere;
+//   - tiles x slices is sized to ~2 blocks per CU, all of the same length (the dispatcher spreads them evenly: tools/census.hip);
+//   - each block writes its partial tile into slab s of a [S][nets][arena] scratch; k_adam_red sums the slabs in a fixed
+//     order (bit-reproducible), adds the vector gradients from the row kernels' partials and applies Adam (+ Polyak).
+struct Tn64Prob {
+  const float* dY; int ldy; long dy_ns; int N;
+  const float* X; int ldx; long x_ns; int K;
+  int w_off, ldw, b_off;                 // weight block / bias inside a net's arena (b_off < 0: none)
+  int tiles_n, tiles_k, tile0;           // tile grid of this problem and its first logical tile (within a net)
+};
+struct Tn64Args {
+  Tn64Prob pr[3]; int nprob; int M; int nets; int S;
+  int tiles_per_net;                     // sum over problems of tiles_n * tiles_k
+  float* Gp; long g_ns;                  // partial slabs [S][nets][g_ns]
+};
+
+// WN x WK waves (WN * WK == 4), each AN x AK MFMA tiles of 16 x 16: block tile = (16 AN WN) x (16 AK WK); TM rows per chunk.
+// VALU work in the loop competes with the f32 MFMAs for the SIMD, so the loop of an INTERIOR block (tile and rows inside
+// the operands: block-uniform) has no masks, scalar chunk bases + per-thread offsets computed once, and LDS addresses that
+// are per-thread constants + immediates; EDGE blocks take the masked, clamped form.
+template <int WN, int WK, int AN, int AK, int TM>
+__global__ __launch_bounds__(256) void k_tn64(Tn64Args p) {
+  constexpr int TN = 16 * AN * WN, TK = 16 * AK * WK, YS_ = TN + 4, XS_ = TK + 4;
+  constexpr int YF = TM * TN / 4 / 256, XF = TM * TK / 4 / 256;      // float4 per thread and chunk
+  constexpr int G = TM / 16;
+  static_assert(WN * WK == 4 && YF >= 1 && XF >= 1 && TM % 16 == 0 && (TM * TN) % 1024 == 0 && (TM * TK) % 1024 == 0, "shape");
+  __shared__ __attribute__((aligned(16))) float Ys[2 * TM * YS_];
+  __shared__ __attribute__((aligned(16))) float Xs[2 * TM * XS_];
+  __shared__ float csum[256];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wn = wave % WN, wk = wave / WN;
+  const int r = lane & 15, kq = lane >> 4;
+  // logical tile: blocks are dealt to the 8 XCDs round-robin; give each XCD a contiguous run of tiles (order: net, problem,
+  // n tile, k tile, slice) so that the operand columns its CUs share are filled into that XCD's L2 once
+  int L = blockIdx.x;
+  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }
+  const int sl = L % p.S; L /= p.S;
+  const int net = L / p.tiles_per_net; L -= net * p.tiles_per_net;
+  int pi = 0;
+  if (p.nprob > 1 && L >= p.pr[1].tile0) pi = 1;
+  if (p.nprob > 2 && L >= p.pr[2].tile0) pi = 2;
+  const Tn64Prob& q = p.pr[pi];
+  L -= q.tile0;
+  const int tn = L / q.tiles_k, tk = L - tn * q.tiles_k;
+  const int n0 = tn * TN, k0 = tk * TK;
+  // this slice's chunks of TM rows: the first (nch % S) slices take one chunk more
+  const int nch = (p.M + TM - 1) / TM, base = nch / p.S, extra = nch % p.S;
+  const int cb = sl * base + min(sl, extra), nc = base + (sl < extra ? 1 : 0);
+  const float* dYn = q.dY + net * q.dy_ns;
+  const float* Xn = q.X + net * q.x_ns;
+  const int Nr = (q.N + 3) & ~3, Kr = (q.K + 3) & ~3;
+  const bool edge = n0 + TN > q.N || k0 + TK > q.K || (cb + nc) * TM > p.M;     // block-uniform
+  STAMP(0);
+  // per-thread constants: element offsets of its float4s inside a chunk, LDS addresses of the parked copies / of its fragments
+  int yo[YF], xo[XF], yl[YF], xl[XF];
+#pragma unroll
+  for (int u = 0; u < YF; ++u) { const int i = t + 256 * u, row = i / (TN / 4), c4 = i % (TN / 4); yo[u] = row * q.ldy + n0 + 4 * c4; yl[u] = row * YS_ + 4 * c4; }
+#pragma unroll
+  for (int u = 0; u < XF; ++u) { const int i = t + 256 * u, row = i / (TK / 4), c4 = i % (TK / 4); xo[u] = row * q.ldx + k0 + 4 * c4; xl[u] = row * XS_ + 4 * c4; }
+  const float* yfrag = Ys + (4 * kq) * YS_ + 16 * AN * wn + r;
+  const float* xfrag = Xs + (4 * kq) * XS_ + 16 * AK * wk + r;
+  float4 ya[YF], xa[XF], yb[YF], xb[XF];
+  f32x4 acc[AN][AK];
+#pragma unroll
+  for (int i = 0; i < AN; ++i)
+#pragma unroll
+    for (int j = 0; j < AK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;                                         // thread (n = t % TN, part = t / TN): column sums of dY (k tile 0 only)
+  const bool want_bias = tk == 0 && q.b_off >= 0;
+
+  auto fetch = [&](auto edge_tag, int c, float4* y, float4* x) {     // raw loads: first touched when parked, two chunks later
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    const int m = (cb + c) * TM;
+    if (!EDGE) {
+      const float* yb_ = dYn + (long)m * q.ldy;                      // scalar bases: the per-thread part is constant
+      const float* xb_ = Xn + (long)m * q.ldx;
+#pragma unroll
+      for (int u = 0; u < YF; ++u) y[u] = ld4(yb_ + yo[u]);
+#pragma unroll
+      for (int u = 0; u < XF; ++u) x[u] = ld4(xb_ + xo[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < YF; ++u) { const int i = t + 256 * u, row = i / (TN / 4), c4 = i % (TN / 4); y[u] = ld4_raw(dYn + (long)min(m + row, p.M - 1) * q.ldy, n0 + 4 * c4, Nr); }
+#pragma unroll
+      for (int u = 0; u < XF; ++u) { const int i = t + 256 * u, row = i / (TK / 4), c4 = i % (TK / 4); x[u] = ld4_raw(Xn + (long)min(m + row, p.M - 1) * q.ldx, k0 + 4 * c4, Kr); }
+    }
+  };
+  auto park = [&](auto edge_tag, int c, int buf, const float4* y, const float4* x) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    const int m = (cb + c) * TM;
+#pragma unroll
+    for (int u = 0; u < YF; ++u) {
+      const int i = t + 256 * u, row = i / (TN / 4), c4 = i % (TN / 4);
+      st4(Ys + buf * TM * YS_ + yl[u], EDGE ? mask4_cols(y[u], n0 + 4 * c4, q.N, m + row < p.M) : y[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < XF; ++u) {
+      const int i = t + 256 * u, row = i / (TK / 4), c4 = i % (TK / 4);
+      st4(Xs + buf * TM * XS_ + xl[u], EDGE ? mask4_cols(x[u], k0 + 4 * c4, q.K, m + row < p.M) : x[u]);
+    }
+  };
+  // fragments of 16-row group g: columns of the parked chunk (4 ds_read_b32 each; conflict-free, row strides = 4 mod 8)
+  auto ldfrag = [&](int buf, int g, float4* a, float4* b) {
+    const float* y0 = yfrag + buf * TM * YS_ + 16 * g * YS_;
+    const float* x0 = xfrag + buf * TM * XS_ + 16 * g * XS_;
+#pragma unroll
+    for (int i = 0; i < AN; ++i) a[i] = make_float4(y0[16 * i], y0[YS_ + 16 * i], y0[2 * YS_ + 16 * i], y0[3 * YS_ + 16 * i]);
+#pragma unroll
+    for (int j = 0; j < AK; ++j) b[j] = make_float4(x0[16 * j], x0[XS_ + 16 * j], x0[2 * XS_ + 16 * j], x0[3 * XS_ + 16 * j]);
+  };
+  auto mfma16 = [&](const float4* a, const float4* b) {     // independent accumulators interleaved: no MFMA waits on its predecessor
+#pragma unroll
+    for (int i = 0; i < AN; ++i)
+#pragma unroll
+      for (int j = 0; j < AK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AN; ++i)
+#pragma unroll
+      for (int j = 0; j < AK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AN; ++i)
+#pragma unroll
+      for (int j = 0; j < AK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AN; ++i)
+#pragma unroll
+      for (int j = 0; j < AK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+  };
+  // group g + 1's fragments are requested before group g's MFMAs (one wave per SIMD: nothing else covers an LDS read)
+  auto compute = [&](int buf) {
+    float4 a0[AN], b0[AK], a1[AN], b1[AK];
+    ldfrag(buf, 0, a0, b0);
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {       // (sched_barrier: the compiler otherwise re-serialises read -> wait -> 4 MFMAs)
+      if (g + 1 < G) ldfrag(buf, g + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < G) ldfrag(buf, g + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < G) mfma16(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_bias) {                                        // (block-uniform)
+      constexpr int PARTS = 256 / TN, RP = TM / PARTS;
+      const float* yc0 = Ys + buf * TM * YS_ + ((t / TN) * RP) * YS_ + (t % TN);
+#pragma unroll
+      for (int i = 0; i < RP; ++i) asum += yc0[i * YS_];
+    }
+  };
+  auto pipeline = [&](auto edge_tag) {
+    // prologue: chunks 0 and 1 requested, chunk 0 parked
+    fetch(edge_tag, 0, ya, xa);
+    if (nc > 1) fetch(edge_tag, 1, yb, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    park(edge_tag, 0, 0, ya, xa);
+    __syncthreads();
+    STAMP(1);
+    for (int c = 0; c < nc; c += 2) {
+      // even chunk c (LDS buffer 0): set A is free (chunk c was parked), chunk c + 1 waits in set B
+      if (c + 2 < nc) fetch(edge_tag, c + 2, ya, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < nc) park(edge_tag, c + 1, 1, yb, xb);
+      __syncthreads();
+      if (c + 1 >= nc) break;
+      // odd chunk c + 1 (LDS buffer 1): set B is free, chunk c + 2 waits in set A
+      if (c + 3 < nc) fetch(edge_tag, c + 3, yb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < nc) park(edge_tag, c + 2, 0, ya, xa);
+      __syncthreads();
+    }
+  };
+  if (edge) pipeline(std::true_type{}); else pipeline(std::false_type{});
+  STAMP(2);
+  // partial tile -> slab `sl` (columns K .. ldw-1 of a weight row are padding: the masked X columns make them exact zeros)
+  float* Gs = p.Gp + ((long)sl * p.nets + net) * p.g_ns;
+#pragma unroll
+  for (int j = 0; j < AK; ++j) {
+    const int col = k0 + 16 * (AK * wk + j) + r;
+    if (col >= q.ldw) continue;
+#pragma unroll
+    for (int i2 = 0; i2 < AN; ++i2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = n0 + 16 * (AN * wn + i2) + 4 * kq + i;
+        if (row < q.N) Gs[q.w_off + (long)row * q.ldw + col] = acc[i2][j][i];
+      }
+  }
+  if (want_bias) {
+    constexpr int PARTS = 256 / TN;
+    csum[t] = asum;
+    __syncthreads();
+    if (t < TN && n0 + t < q.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < PARTS; ++i) v += csum[i * TN + t];
+      Gs[q.b_off + n0 + t] = v;
+    }
+  }
+  STAMP(3);
+}
+
+// Sum of the split-M partial slabs + the vector gradients the row kernels left as per-row-block partials, then the
+// optimiser step of torch.optim.Adam (agents/agent.py:236,286) and the Polyak update of the same element (agents/agent.py:328).
+// Sources by offset range: `vec` ranges come from part[net][blk][slot][256] summed over the row blocks (16 threads per
+// float4, DPP-reduced), one scalar from part_s[net][blk][0], everything else from the S <= 8 slabs.  Sums run in a fixed
+// order, so replays are bit-reproducible.
+struct AdamRedVec { int off; int slot; };
+struct AdamRedArgs {
+  const float* Gp; int S; int nets; long g_ns;           // slabs [S][nets][g_ns]
+  float* G;                                              // gradient arena (always written)
+  int apply; float* P; float* Mo; float* Vo; float* T; float tau;
+  const float* adam; float b1, b2, eps;
+  AdamRedVec vec[5]; int nvec; int vec_nblk;             // 256-wide vectors finalised from row-block partials
+  const float* part; int pstride;
+  int s_off; int s_nblk; const float* part_s;            // one scalar element (critic head bias), s_off < 0: none
+  const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
+};
+__device__ __forceinline__ void adam_red_commit(const AdamRedArgs& a, long off, float4 g, float4 w, float4 m, float4 v, float4 tt, float step, float sq2) {
+  st4(a.G + off, g);
+  if (a.apply) {
+    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
+    m = m + (g - m) * omb1;
+    v = v * a.b2 + g * g * omb2;
+    w.x -= step * (m.x / (sqrtf(v.x) / sq2 + a.eps)); w.y -= step * (m.y / (sqrtf(v.y) / sq2 + a.eps));
+    w.z -= step * (m.z / (sqrtf(v.z) / sq2 + a.eps)); w.w -= step * (m.w / (sqrtf(v.w) / sq2 + a.eps));
+    st4(a.Mo + off, m); st4(a.Vo + off, v); st4(a.P + off, w);
+    if (a.T) st4(a.T + off, tt + (w - tt) * a.tau);
+  }
+}
+// grid = (main blocks + 4 nvec vector blocks + 1 scalar block, nets); main blocks = ceil(g_ns / 1024)
+__global__ __launch_bounds__(256) void k_adam_red(AdamRedArgs a) {
+  const int net = blockIdx.y, t = threadIdx.x;
+  const int main_blocks = (int)((a.g_ns / 4 + 255) / 256);
+  const float step = a.apply ? a.adam[0] : 0.f, sq2 = a.apply ? a.adam[1] : 1.f;
+  const bool extras = blockIdx.x == 0 && net == 0 && t < 64;
+  float loss_acc = 0.f; int tick_v = 0;
+  if (extras) {
+    if (a.loss_dst) for (int k = t; k < a.loss_n; k += 64) loss_acc += a.loss_part[(long)k * a.loss_stride + a.loss_off];
+    if (t == 0 && a.tick) tick_v = *a.tick;
+  }
+  const int bx = blockIdx.x;
+  if (bx < main_blocks) {
+    // slab-sourced elements: one float4 per thread (the vector ranges and the scalar's float4 belong to the blocks below)
+    const long i = ((long)bx * 256 + t) * 4;
+    bool mine = i < a.g_ns && !(a.s_off >= 0 && i == a.s_off);
+#pragma unroll
+    for (int e = 0; e < 5; ++e)
+      if (e < a.nvec && i >= a.vec[e].off && i < a.vec[e].off + HID) mine = false;
+    if (mine) {
+      const long off = net * a.g_ns + i;
+      float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
+      if (a.apply) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+      float4 gs[8];
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) gs[sl] = ld4(a.Gp + ((long)min(sl, a.S - 1) * a.nets + net) * a.g_ns + i);   // all requests first
+      float4 g = gs[0];
+#pragma unroll
+      for (int sl = 1; sl < 8; ++sl) if (sl < a.S) g = g + gs[sl];
+      adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
+    }
+  } else if (bx < main_blocks + 4 * a.nvec) {
+    // one quarter of a 256-wide vector gradient: float4 column (t >> 4) + 16 quarter, 16 threads share its row-block partials
+    const int e = (bx - main_blocks) >> 2, quarter = (bx - main_blocks) & 3;
+    int voff = a.vec[0].off, vslot = a.vec[0].slot;
+    if (e == 1) { voff = a.vec[1].off; vslot = a.vec[1].slot; }
+    if (e == 2) { voff = a.vec[2].off; vslot = a.vec[2].slot; }
+    if (e == 3) { voff = a.vec[3].off; vslot = a.vec[3].slot; }
+    if (e == 4) { voff = a.vec[4].off; vslot = a.vec[4].slot; }
+    const int c4 = (t >> 4) + 16 * quarter, sub = t & 15;
+    const long off = net * a.g_ns + voff + 4 * c4;
+    float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
+    if (a.apply && sub == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+    const float* pp = a.part + ((long)net * a.pstride * NSLOT + vslot) * HID + 4 * c4;
+    float4 g = f4(0.f);
+    for (int blk = sub; blk < a.vec_nblk; blk += 64) {     // 4 independent requests per trip (one trip up to B = 1024)
+      const int nb = a.vec_nblk;
+      const float4 v0 = ld4(pp + (long)blk * NSLOT * HID), v1 = ld4(pp + (long)min(blk + 16, nb - 1) * NSLOT * HID);
+      const float4 v2 = ld4(pp + (long)min(blk + 32, nb - 1) * NSLOT * HID), v3 = ld4(pp + (long)min(blk + 48, nb - 1) * NSLOT * HID);
+      g = g + v0;
+      if (blk + 16 < nb) g = g + v1;
+      if (blk + 32 < nb) g = g + v2;
+      if (blk + 48 < nb) g = g + v3;
+    }
+    g.x = row16_sum(g.x); g.y = row16_sum(g.y); g.z = row16_sum(g.z); g.w = row16_sum(g.w);
+    if (sub == 0) adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
+  } else if (a.s_off >= 0 && t < 64) {
+    // the scalar element (critic head bias) and the 3 padding floats behind it
+    const long off = net * a.g_ns + a.s_off;
+    float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
+    if (a.apply && t == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+    float sg = 0.f;
+    for (int blk = t; blk < a.s_nblk; blk += 64) sg += a.part_s[((long)net * a.pstride + blk) * 2];
+    sg = wave_sum(sg);
+    if (t == 0) adam_red_commit(a, off, make_float4(sg, 0.f, 0.f, 0.f), w, m, v, tt, step, sq2);
+  }
+  if (extras) {
+    if (a.loss_dst) {
+      const float s = wave_sum(loss_acc);
+      if (t == 0) *a.loss_dst = s * a.loss_scale;
+    }
+    if (t == 0 && a.tick) *a.tick = tick_v + 1;
   }
 }
 
