@@ -119,7 +119,7 @@ struct sactd3_engine {
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
-  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0;
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
   // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
@@ -335,7 +335,13 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
 }
 
 static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets) {
-  if (g.M >= BIG_BATCH && e->Gp && !e->tune_tn_kt) return launch_tn64(e, s, name, g, nets);
+  if (g.M >= BIG_BATCH && e->Gp && !e->tune_tn_kt) {
+    // the split-M form pays an extra node (k_adam_red): taken when the launch has enough 64 x 32 tiles to fill the chip with
+    // long slices (the critics' 168 at Humanoid: 25.6 -> 18.6 us); the actor's 88 tiles gain nothing (14.3 vs 14.4 us)
+    int tiles = 0;
+    for (int i = 0; i < g.nprob; ++i) tiles += ((g.pr[i].N + TN64_N - 1) / TN64_N) * ((g.pr[i].ldw + TN64_K - 1) / TN64_K);
+    if (tiles * nets >= e->tune_tn64_min) return launch_tn64(e, s, name, g, nets);
+  }
   auto count = [&](int kt) {
     int tiles = 0;
     for (int i = 0; i < g.nprob; ++i) {
@@ -799,6 +805,8 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
+  e->tune_tn64_min = e->num_cus / 2;
+  if (const char* f = getenv("SACTD3_TN64_MIN")) e->tune_tn64_min = atoi(f);
   if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) e->tune_tn_kt = v; }
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 

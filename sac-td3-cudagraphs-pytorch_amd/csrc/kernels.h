@@ -40,9 +40,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic builds only (tools/kprobe.hip): shader-clock stamps of the LAST block's thread 0 at phase boundaries.
 #ifdef SACTD3_STAMPS
 __device__ long long g_stamps[16];
+__device__ long long g_phase[8];
+#define PHASE_DECL long long ph_t = 0, ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PHASE_START do { __builtin_amdgcn_s_waitcnt(0xc07f); ph_t = clock64(); } while (0)
+#define PHASE(i) do { const long long n_ = clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PHASE_DRAIN(i) do { __builtin_amdgcn_s_waitcnt(0); const long long n_ = clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PHASE_OUT do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) for (int i_ = 0; i_ < 6; ++i_) g_phase[i_] = ph_acc[i_]; } while (0)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0) { __builtin_amdgcn_s_waitcnt(0); g_stamps[i] = clock64(); } } while (0)
 #else
 #define STAMP(i)
+#define PHASE_DECL
+#define PHASE_START
+#define PHASE(i)
+#define PHASE_DRAIN(i)
+#define PHASE_OUT
 #endif
 
 struct DevCtl {
@@ -754,19 +765,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
 #pragma unroll
     for (int u = 0; u < RW; ++u) rw[u] = ld4_raw(wp[u], k, Kr);
   };
+  // (Measured inside the Humanoid iteration, full-iteration A/B on one box: a uniform "full chunk: skip the masks" branch here
+  //  costs 11 us per iteration -- the compiler then waits for the loads in front of the branch -- and parking the next chunk
+  //  BEFORE the MFMAs, with fragments requested a k step ahead, 4.5 us, although each looks cheaper on paper.)
   auto park = [&](int buf, int c) {
     const int k = c * KC64 + sc;
-    if ((c + 1) * KC64 <= p.K) {                  // (uniform) a full chunk: no masks -- VALU work competes with the f32 MFMAs
 #pragma unroll
-      for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, ra[u]);
+    for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(ra[u], k, p.K));
 #pragma unroll
-      for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, rw[u]);
-    } else {
-#pragma unroll
-      for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(ra[u], k, p.K));
-#pragma unroll
-      for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(rw[u], k, p.K));
-    }
+    for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, mask4_cols(rw[u], k, p.K));
   };
   STAMP(0);
   fetch(0);

@@ -26,11 +26,13 @@ static void show(const char* name, double us, int n) {
   long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
   printf("%-44s %6.2f us/launch | last block phases (cycles):", name, us);
   for (int i = 1; i < n; ++i) printf(" %lld", h[i] - h[i - 1]);
-  printf("\n");
+  long long ph[8]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph));
+  printf(" | loop: issue+mfma %lld drain %lld barrier %lld\n", ph[0], ph[1], ph[2]);
 }
 
 struct Shapes { int nets; int nprob; int N[3], K[3], ldw[3]; };
 
+static int g_light = 0;   // "pmc" mode: few plain launches per variant (for rocprofv3 --pmc)
 static int g_ld256 = 256;   // row stride (floats) of the 256-wide operands: 256 as in the engine, or padded (channel-conflict experiment)
 template <int WN, int WK, int AN, int AK, int TM>
 static int run(hipStream_t s, const char* label, const Shapes& sh, int M, float* dY, float* X, float* Gp, int S_override) {
@@ -51,13 +53,20 @@ static int run(hipStream_t s, const char* label, const Shapes& sh, int M, float*
   S = std::max(1, std::min(S, std::min(8, nch)));
   a.S = S;
   const dim3 grid(tiles * sh.nets * S);
+  if (g_light) {
+    for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k_tn64<WN, WK, AN, AK, TM>), grid, dim3(256), 0, s, a);
+    hipStreamSynchronize(s);
+    printf("%s tile %dx%d TM=%d S=%d blocks=%d\n", label, TN, TK, TM, S, grid.x);
+    return 0;
+  }
   double us = graph_us(s, [&] { hipLaunchKernelGGL((k_tn64<WN, WK, AN, AK, TM>), grid, dim3(256), 0, s, a); }, 20, 30);
   char nm[128]; snprintf(nm, 128, "%s tile %dx%d TM=%d S=%d blocks=%d", label, TN, TK, TM, S, grid.x);
   show(nm, us, 4);
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  g_light = argc > 1;
   hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   const int M = 1024;
   float *dY, *X, *Gp;
@@ -71,7 +80,13 @@ int main() {
     const Shapes& sh = (pass & 1) == 0 ? critics : actor;
     g_ld256 = pass < 2 ? 256 : 272;
     const char* lb = pass == 0 ? "critics ld256" : (pass == 1 ? "actor ld256" : (pass == 2 ? "critics ld272" : "actor ld272"));
+    if (g_light && pass != 0) break;
     for (int S : {0, 2}) {
+      if (g_light) {
+        if (S == 0) run<2, 2, 2, 1, 64>(s, lb, sh, M, dY, X, Gp, 0);
+        else { run<2, 2, 2, 2, 64>(s, lb, sh, M, dY, X, Gp, 2); run<2, 2, 4, 2, 32>(s, lb, sh, M, dY, X, Gp, 2); }
+        continue;
+      }
       run<4, 1, 1, 2, 32>(s, lb, sh, M, dY, X, Gp, S);
       run<4, 1, 1, 2, 64>(s, lb, sh, M, dY, X, Gp, S);
       run<2, 2, 2, 1, 32>(s, lb, sh, M, dY, X, Gp, S);
