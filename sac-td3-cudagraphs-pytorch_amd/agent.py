@@ -142,6 +142,8 @@ class Agent:
         scale, bias = (self.max_ac - self.min_ac) / 2.0, (self.max_ac + self.min_ac) / 2.0
         actor = schema.flat_to_dict(e.get_params(_lib.ACTOR), self.ob_dim, self._nh(), self.ln)
         actor["action_scale"], actor["action_bias"] = np.broadcast_to(scale, (self.ac_dim,)).copy(), np.broadcast_to(bias, (self.ac_dim,)).copy()
+        if self.td3:   # agents/nets.py:139-141: the TD3 actor registers its exploration sigma as a third buffer
+            actor["exploration_noise"] = np.asarray(e.cfg.actor_noise_std, np.float32)
         q = e.get_params(_lib.CRITICS).reshape(2, -1)
         return {"actor": actor,
                 "qnet1": schema.flat_to_dict(q[0], self.ob_dim + self.ac_dim, 1, self.ln),
@@ -189,13 +191,53 @@ class Agent:
         if do_actor:
             self.actor_updates_so_far += self.engine.cfg.actor_update_delay
 
-    # -- checkpoints (agents/agent.py:333-371), reference .pth schema with live critic weights
+    # -- checkpoints (agents/agent.py:333-371): the reference's .pth schema, with LIVE critic weights
+    def _plain_hps(self) -> Dict[str, Any]:
+        """`hps` as a plain mapping of builtin scalars (the reference stores its DictConfig object, agents/agent.py:343:
+        only a pickling loader can read that back; a plain dict also loads with torch.load(weights_only=True))."""
+        h = self.hps
+        try:
+            items = dict(h).items() if hasattr(h, "keys") else vars(h).items()
+        except TypeError:
+            items = {}
+        return {str(k): v for k, v in items if isinstance(v, (bool, int, float, str)) or v is None}
+
+    def _adam_state_dict(self, which: int, shapes, lr: float, stacked: int):
+        """torch.optim.Adam.state_dict() of the optimiser that owns `which`, in the reference's form: parameters in
+        `module.parameters()` order (= state_dict order), the twin critics as the dense-stacked [2, ...] tensors of
+        agents/agent.py:106-119 under ONE Adam instance, per-parameter `step` / `exp_avg` / `exp_avg_sq`, torch's own
+        `param_groups`.  Built by filling a real torch.optim.Adam, so the layout is whatever this torch version writes."""
+        import torch
+        m, v, step = self.engine.get_adam_state(which)
+        m, v = m.reshape(max(stacked, 1), -1), v.reshape(max(stacked, 1), -1)
+        params, off = [], 0
+        mv = []
+        for _, shp in shapes:
+            n = int(np.prod(shp))
+            full = ((stacked,) if stacked else ()) + tuple(shp)
+            params.append(torch.nn.Parameter(torch.zeros(full)))
+            take = (lambda a: a[:, off:off + n].reshape(full)) if stacked else (lambda a: a[0, off:off + n].reshape(full))
+            mv.append((torch.from_numpy(np.ascontiguousarray(take(m))), torch.from_numpy(np.ascontiguousarray(take(v)))))
+            off += n
+        opt = torch.optim.Adam(params, lr=lr, betas=(self.engine.cfg.adam_beta1, self.engine.cfg.adam_beta2), eps=self.engine.cfg.adam_eps)
+        if step > 0:                                   # torch creates the state lazily, at the first step
+            for p_, (m_, v_) in zip(params, mv):
+                opt.state[p_] = {"step": torch.tensor(float(step)), "exp_avg": m_, "exp_avg_sq": v_}
+        return opt.state_dict()
+
     def save(self, path: Path, sfx: Optional[str] = None) -> Path:
+        """agents/agent.py:333-358 (wandb upload aside): keys `hps`, `timesteps_so_far`, `actor`, `qnet1`, `qnet2`,
+        `actor_optimizer`, `q_optimizer` as the reference writes them -- its own `load_from_disk` (:360-371) accepts the file --
+        plus `engine_resume` (what the reference does not save: targets, log_alpha and its optimiser, every step count) for
+        a bit-exact resume of this engine."""
         import torch
         fname = f"ckpt_{sfx}" if sfx is not None else f".ckpt_{self.timesteps_so_far}ts"
         path = Path(path) / f"{fname}.pth"
         sds = {k: {kk: torch.from_numpy(np.ascontiguousarray(vv)) for kk, vv in v.items()} for k, v in self.state_dicts().items()}
-        e = self.engine
+        e, c = self.engine, self.engine.cfg
+        ck = {"hps": self._plain_hps(), "timesteps_so_far": self.timesteps_so_far, **sds,
+              "actor_optimizer": self._adam_state_dict(_lib.ACTOR, schema.net_keys(self.ob_dim, self._nh(), self.ln), c.actor_lr, 0),
+              "q_optimizer": self._adam_state_dict(_lib.CRITICS, schema.net_keys(self.ob_dim + self.ac_dim, 1, self.ln), c.qnets_lr, 2)}
         extra = {}
         for name, which in (("actor", _lib.ACTOR), ("critics", _lib.CRITICS), ("log_alpha", _lib.LOG_ALPHA)):
             m, v, step = e.get_adam_state(which)
@@ -203,23 +245,51 @@ class Agent:
         extra["actor_target"] = torch.from_numpy(e.get_params(_lib.ACTOR_TARGET))
         extra["critics_target"] = torch.from_numpy(e.get_params(_lib.CRITICS_TARGET))
         extra["log_alpha"] = float(e.get_params(_lib.LOG_ALPHA)[0])
-        torch.save({"timesteps_so_far": self.timesteps_so_far, **sds, "engine_resume": extra}, path)
+        ck["engine_resume"] = extra
+        torch.save(ck, path)
         return path
 
+    @staticmethod
+    def _adam_from_state_dict(sd, stacked: int):
+        """(exp_avg flat, exp_avg_sq flat, step) in the engine's layout from a torch Adam state_dict (see _adam_state_dict)."""
+        st = sd["state"]
+        if not st:
+            return None
+        idx = sorted(st)
+        f = lambda key: np.concatenate([st[i][key].detach().cpu().numpy().astype(np.float32).reshape(max(stacked, 1), -1) for i in idx], 1).reshape(-1)
+        return f("exp_avg"), f("exp_avg_sq"), int(round(float(st[idx[0]]["step"])))
+
     def load_from_disk(self, path: Path) -> None:
+        """agents/agent.py:360-371.  Reads files written by `save` above and any file in the reference's schema that a
+        weights-only loader accepts (state_dicts + optimiser state_dicts of tensors and builtin scalars).  A .pth written
+        by the reference itself pickles its OmegaConf DictConfig under `hps`: torch.load(weights_only=True) refuses it,
+        and this loader is deliberately not loosened."""
         import torch
         ck = torch.load(path, weights_only=True)
         if "timesteps_so_far" in ck:
             self.timesteps_so_far = ck["timesteps_so_far"]
         actor = schema.dict_to_flat(ck["actor"], self.ob_dim, self._nh(), self.ln)
         q = [schema.dict_to_flat(ck[k], self.ob_dim + self.ac_dim, 1, self.ln) for k in ("qnet1", "qnet2")]
-        self.load_flat(actor, np.concatenate(q), also_targets="engine_resume" not in ck)
         ex = ck.get("engine_resume")
+        e = self.engine
+        n_a, n_c = e.param_count(_lib.ACTOR), e.param_count(_lib.CRITICS)
+        if ex:   # validate before touching the engine: a blob from other dims / layer_norm setting must not reach the C side
+            for name, n in (("actor", n_a), ("critics", n_c), ("log_alpha", 1)):
+                st = ex[f"adam/{name}"]
+                if st["exp_avg"].numel() != n or st["exp_avg_sq"].numel() != n:
+                    raise ValueError(f"engine_resume: adam/{name} holds {st['exp_avg'].numel()} values, this agent needs {n}")
+            if ex["actor_target"].numel() != n_a or ex["critics_target"].numel() != n_c:
+                raise ValueError("engine_resume: target networks of another shape")
+        self.load_flat(actor, np.concatenate(q), also_targets=not ex)
         if ex:
-            e = self.engine
             e.set_params(_lib.ACTOR_TARGET, ex["actor_target"].numpy())
             e.set_params(_lib.CRITICS_TARGET, ex["critics_target"].numpy())
             e.set_params(_lib.LOG_ALPHA, np.array([ex["log_alpha"]], np.float32))
             for name, which in (("actor", _lib.ACTOR), ("critics", _lib.CRITICS), ("log_alpha", _lib.LOG_ALPHA)):
                 st = ex[f"adam/{name}"]
                 e.set_adam_state(which, st["exp_avg"].numpy(), st["exp_avg_sq"].numpy(), int(st["step"]))
+        else:    # the reference's own keys only (agents/agent.py:368-369): optimiser moments and step counts
+            for key, which, stacked in (("actor_optimizer", _lib.ACTOR, 0), ("q_optimizer", _lib.CRITICS, 2)):
+                got = self._adam_from_state_dict(ck[key], stacked) if key in ck else None
+                if got is not None:
+                    e.set_adam_state(which, *got)

@@ -3,7 +3,8 @@ be driven end to end without tensordict / torchrl / gymnasium being importable:
 
   segment()     rollout generator                      orchestrator.py:42-118   
   train()       the training loop's control flow       orchestrator.py:317-352 (+ counters :326,342,349)
-  episode()     evaluation-episode generator           orchestrator.py:121-246 (lengths / returns only)
+  episode()     evaluation-episode generator           orchestrator.py:121-246 (lengths / returns, trajectories with need_lists; no pixels)
+  evaluate()    offline evaluation of a checkpoint     orchestrator.py:415-481 (trajectory files as .npz)
   Evaluator     the eval block of the loop             orchestrator.py:303-305,354-403 (rolling window, best model, speed)
   Tabular       key/value progress files               helpers/logger.py:93-150 (progress.json lines, progress.csv, text table)
 
@@ -201,26 +202,102 @@ class Evaluator:
         return out
 
 
-def episode(env, agent, seed: int) -> Generator[Dict[str, np.ndarray], None, None]:
-    """orchestrator.py:121-246 without trajectory lists / pixels: one evaluation episode per `next()`, greedy
-    actions (`explore=False`, :165-173), episode statistics taken from `infos["final_info"]` (:197-201), the env
-    re-seeded per episode from a generator seeded with `seed` (:136-140,238)."""
+class _Trajectory:
+    """The per-step record of one evaluation episode (`need_lists=True`, orchestrator.py:143-148,179-195).  Columns are
+    plain Python lists while the episode runs and become numpy arrays when it ends (the reference's reason: list.append is
+    cheap).  Layout quirks kept on purpose: every entry keeps the vector-env's leading axis of size 1; `observations` is
+    the reset observation followed by every non-final `new_ob`, `next_observations` every `new_ob` -- so the last one is
+    the auto-reset observation of the NEXT episode, not the final observation of this one."""
+
+    KEYS = ("observations", "actions", "next_observations", "rewards", "terminations", "dones")
+
+    def __init__(self):
+        self.cols: Dict[str, list] = {k: [] for k in self.KEYS}
+
+    def begin(self, ob) -> None:
+        self.cols = {k: [] for k in self.KEYS}
+        self.cols["observations"].append(ob)
+
+    def step(self, action, new_ob, reward, termination, done) -> None:
+        c = self.cols
+        c["next_observations"].append(new_ob)
+        c["actions"].append(action)
+        c["rewards"].append(reward)
+        c["terminations"].append(termination)
+        c["dones"].append(done)
+        if not done:
+            c["observations"].append(new_ob)
+
+    def arrays(self) -> Dict[str, np.ndarray]:
+        return {k: np.array(v) for k, v in self.cols.items()}
+
+
+def episode(env, agent, seed: int, *, need_lists: bool = False) -> Generator[Dict[str, np.ndarray], None, None]:
+    """orchestrator.py:121-246 without pixels: one evaluation episode per `next()` on a ONE-env vector env, greedy actions
+    (`explore=False`, :165-173), episode statistics taken from `infos["final_info"]` (:197-201), the env re-seeded before
+    every episode from a generator seeded with `seed` (:136-140,152,238).  `need_lists=True` adds the trajectory (see
+    _Trajectory) to the yielded dict, as `evaluate()` consumes it (:446-457)."""
     rng = np.random.default_rng(seed)
 
-    def randomize_seed() -> int:
-        return seed + rng.integers(2 ** 32 - 1, size=1).item()
+    def fresh_episode():
+        ob, _ = env.reset(seed=seed + rng.integers(2 ** 32 - 1, size=1).item())
+        return ob
 
-    ob, _ = env.reset(seed=randomize_seed())
+    traj = _Trajectory() if need_lists else None
+    ob = fresh_episode()
+    if traj:
+        traj.begin(ob)
     while True:
         action = agent.predict({"observations": np.asarray(ob, np.float32)}, explore=False)
-        ob, _reward, _termination, _truncation, infos = env.step(action)
+        new_ob, reward, termination, truncation, infos = env.step(action)
+        done = bool(np.asarray(termination).any() or np.asarray(truncation).any())
+        if traj:
+            traj.step(action, new_ob, reward, termination, np.asarray(done) if np.ndim(termination) == 0 else np.asarray(termination) | np.asarray(truncation), )
+        ob = new_ob
         if "final_info" in infos:
-            for info in infos["final_info"]:
-                if info is None:
-                    continue
-                ep_len, ep_ret = float(np.asarray(info["episode"]["l"]).item()), float(np.asarray(info["episode"]["r"]).item())
-            yield {"length": np.array(ep_len), "return": np.array(ep_ret)}
-            ob, _ = env.reset(seed=randomize_seed())
+            stats = [i["episode"] for i in infos["final_info"] if i is not None][-1]
+            out = traj.arrays() if traj else {}
+            out["length"] = np.array(float(np.asarray(stats["l"]).item()))
+            out["return"] = np.array(float(np.asarray(stats["r"]).item()))
+            yield out
+            ob = fresh_episode()
+            if traj:
+                traj.begin(ob)
+
+
+def evaluate(cfg: Any, env, agent, name: str = "eval", tabular: Optional[Tabular] = None) -> Dict[str, float]:
+    """orchestrator.py:415-481 without wandb / pixels: optionally restore a checkpoint (`cfg.load_ckpt`: a local .pth path
+    for `agent.load_from_disk`; the reference downloads it from wandb, :430), play `cfg.num_episodes` greedy episodes, and
+    with `cfg.gather_trajectories` write each one under `cfg.trajectory_dir / name` as `{i:03d}_L{length}_R{return}.npz`
+    (the reference writes the same arrays with TensorDict.to_h5, :446-457; h5py / tensordict are not in this image) after
+    checking that every column has `length` rows (:450-451) and casting float64 columns to float32 (:454-456).  Returns the
+    mean length / return (:473-476, float32 means) and records them in `tabular` (:478-481)."""
+    traj_dir = None
+    if getattr(cfg, "gather_trajectories", False):
+        traj_dir = Path(cfg.trajectory_dir) / name
+        traj_dir.mkdir(parents=True, exist_ok=True)
+    ckpt = getattr(cfg, "load_ckpt", None)
+    if ckpt:
+        agent.load_from_disk(Path(ckpt))
+    ep_gen = episode(env, agent, cfg.seed, need_lists=traj_dir is not None)
+    lens, rets = [], []
+    for i in range(cfg.num_episodes):
+        ep = next(ep_gen)
+        lens.append(ep["length"])
+        rets.append(ep["return"])
+        if traj_dir is not None:
+            n = int(ep["length"])
+            cols = {k: v for k, v in ep.items() if k not in ("length", "return")}
+            for k, v in cols.items():
+                assert v.shape[0] == n, f"wrong array length for {k=}"
+            cols = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in cols.items()}
+            np.savez(traj_dir / f"{str(i).zfill(3)}_L{n}_R{int(ep['return'])}.npz", length=ep["length"], **{"return": ep["return"]}, **cols)
+    out = {"length": float(np.asarray(lens, np.float32).mean()), "return": float(np.asarray(rets, np.float32).mean())}
+    if tabular is not None:
+        for k, v in out.items():
+            tabular.record(k, v)
+        tabular.dump()
+    return out
 
 
 class _Box:

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.sac_td3_ref import Hps, QNet, SquashedGaussPolicy
+from oracle.sac_td3_ref import DetPolicy, Hps, QNet, RefAgent, SquashedGaussPolicy
 
 pytestmark = pytest.mark.gpu
 P = pytest.importorskip("sac_td3_cudagraphs_pytorch_amd")
@@ -99,3 +99,90 @@ def test_long_run_with_ring_wraparound_stays_finite():
     assert all(np.isfinite(v) for v in m.values()) and 0 < m["vitals/alpha"] < 10, m
     for which in (_lib.ACTOR, _lib.CRITICS, _lib.CRITICS_TARGET):
         assert np.isfinite(agent.engine.get_params(which)).all()
+
+
+@pytest.mark.parametrize("algo", ["sac", "td3"])
+def test_checkpoint_carries_the_reference_optimizer_keys(tmp_path, algo):
+    """agents/agent.py:342-351,368-369: `actor_optimizer` / `q_optimizer` are torch.optim.Adam state_dicts (critics as the
+    stacked [2, ...] tensors under one Adam, agents/agent.py:106-119), `hps` a plain mapping; the TD3 actor dict has the
+    `exploration_noise` buffer (agents/nets.py:139-141).  Check: (i) strict load_state_dict into the oracle's modules (pinned
+    to the reference's classes); (ii) torch.optim.Adam over the oracle's parameters accepts the optimiser state_dicts and
+    ONE more oracle step equals ONE more engine step on the same batch and noise; (iii) a second engine that reads ONLY the
+    reference's keys (engine_resume stripped) continues with the same Adam moments and step counts."""
+    agent, o, a = _agent(algo, B=64, cap=1000)
+    g = torch.Generator().manual_seed(3)
+    rows = dict(observations=torch.randn(500, o, generator=g), actions=torch.rand(500, a, generator=g) * 2 - 1, rewards=torch.randn(500, generator=g),
+                next_observations=torch.randn(500, o, generator=g), dones=torch.zeros(500, dtype=torch.bool))
+    agent.rb.extend(rows)
+    for i in range(6):
+        agent.iteration(i)
+    path = agent.save(tmp_path, sfx="best")
+    ck = torch.load(path, weights_only=True)
+    assert {"hps", "timesteps_so_far", "actor", "qnet1", "qnet2", "actor_optimizer", "q_optimizer"} <= set(ck)
+    assert isinstance(ck["hps"], dict) and ck["hps"]["batch_size"] == 64 and ck["hps"]["prefer_td3_over_sac"] == (algo == "td3")
+    lo, hi = torch.full((a,), -1.0), torch.full((a,), 1.0)
+    hps = (Hps.td3 if algo == "td3" else Hps.sac)(batch_size=64)
+    ref = RefAgent(o, a, lo, hi, hps)
+    ref.actor.load_state_dict(ck["actor"])                                   # strict, incl. the TD3 exploration_noise buffer
+    for qn, key in zip(ref.qnets, ("qnet1", "qnet2")):
+        qn.load_state_dict(ck[key])
+    if algo == "td3":
+        assert isinstance(ref.actor, DetPolicy) and float(ck["actor"]["exploration_noise"]) == pytest.approx(0.1)
+    # (ii) the optimiser state_dicts: actor as is; the critics' stacked [2, ...] entries split over the oracle's two modules
+    ref.actor_optimizer.load_state_dict(ck["actor_optimizer"])
+    qsd = ck["q_optimizer"]
+    n_per = len(list(ref.qnets[0].parameters()))
+    assert sorted(qsd["state"]) == list(range(n_per)) and qsd["state"][0]["exp_avg"].shape[0] == 2
+    split = {"state": {}, "param_groups": [dict(qsd["param_groups"][0], params=list(range(2 * n_per)))]}
+    for net in range(2):
+        for i in range(n_per):
+            st = qsd["state"][i]
+            split["state"][net * n_per + i] = {"step": st["step"].clone(), "exp_avg": st["exp_avg"][net].clone(), "exp_avg_sq": st["exp_avg_sq"][net].clone()}
+    ref.q_optimizer.load_state_dict(split)
+    assert float(qsd["state"][0]["step"]) == 6 and float(ck["actor_optimizer"]["state"][0]["step"]) == 4
+    assert qsd["param_groups"][0]["lr"] == pytest.approx(hps.qnets_lr) and ck["actor_optimizer"]["param_groups"][0]["lr"] == pytest.approx(hps.actor_lr)
+    # one more critic step on both sides, same batch and noise
+    b = {k: v[:64] for k, v in rows.items()}
+    eps = torch.randn(64, a, generator=g)
+    ex = ck["engine_resume"]
+    ref.qnets_target.load_state_dict(ref.qnets.state_dict())
+    from tests.test_gpu_engine import flat_critics, flat_actor
+    eng = agent.engine
+    eng.set_params(_lib.CRITICS_TARGET, flat_critics(ref, ref.qnets))            # both sides: targets := online critics
+    if algo == "td3":
+        ref.actor_target.load_state_dict(ref.actor.state_dict()); eng.set_params(_lib.ACTOR_TARGET, flat_actor(ref, ref.actor))
+    else:
+        ref.log_alpha.data.fill_(ex["log_alpha"])
+    eng.load_batch(b["observations"], b["actions"], b["rewards"], b["next_observations"], b["dones"])
+    eng.set_noise(_lib.SITE_CRITIC, eps)
+    eng.update_qnets()
+    out = ref.update_qnets(ref.to_batch(b["observations"], b["actions"], b["rewards"], b["next_observations"], b["dones"]), eps)
+    np.testing.assert_allclose(eng.read_metrics()["loss/qf_loss"], float(out["loss/qf_loss"]), rtol=1e-5, atol=1e-5)
+    from tests.helpers import assert_params_close
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), hps.qnets_lr, 1, "critics after the 7th Adam step (moments from the checkpoint)")
+    # (iii) the reference's keys alone restore the optimiser moments in a fresh engine
+    ref_only = {k: v for k, v in ck.items() if k != "engine_resume"}
+    p2 = tmp_path / "ref_keys_only.pth"
+    torch.save(ref_only, p2)
+    other, _, _ = _agent(algo, B=64, cap=1000, seed=5)
+    other.load_from_disk(p2)
+    m0, v0, t0 = ex["adam/critics"]["exp_avg"].numpy(), ex["adam/critics"]["exp_avg_sq"].numpy(), ex["adam/critics"]["step"]
+    m1, v1, t1 = other.engine.get_adam_state(_lib.CRITICS)
+    assert t1 == t0 == 6 and np.array_equal(m1, m0) and np.array_equal(v1, v0)
+    ma, va, ta = other.engine.get_adam_state(_lib.ACTOR)
+    assert ta == 4 and np.array_equal(ma, ex["adam/actor"]["exp_avg"].numpy())
+    assert np.array_equal(other.engine.get_params(_lib.CRITICS_TARGET), other.engine.get_params(_lib.CRITICS))   # targets = clones (agents/agent.py:64,107)
+
+
+def test_load_refuses_a_resume_blob_of_another_shape(tmp_path):
+    agent, o, a = _agent("sac", B=32, cap=200)
+    path = agent.save(tmp_path, sfx="x")
+    ck = torch.load(path, weights_only=True)
+    ck["engine_resume"]["adam/critics"]["exp_avg"] = ck["engine_resume"]["adam/critics"]["exp_avg"][:-8]
+    torch.save(ck, path)
+    before = agent.engine.get_params(_lib.CRITICS)
+    with pytest.raises(ValueError):
+        agent.load_from_disk(path)
+    assert np.array_equal(agent.engine.get_params(_lib.CRITICS), before)        # nothing was written
+    with pytest.raises(ValueError):
+        agent.engine.set_adam_state(_lib.CRITICS, np.zeros(5, np.float32), np.zeros(5, np.float32), 1)

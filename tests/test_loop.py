@@ -151,3 +151,101 @@ def test_evaluator_window_best_model_and_speed(tmp_path):
     import json
     rows = [json.loads(x) for x in (tmp_path / "progress.json").read_text().splitlines()]
     assert len(rows) == 26 and list(rows[0]) == ["timestep", "length", "return", "speed"]
+
+
+# ------------------------------------------------------------------------------------------ evaluation side (F3)
+from oracle.eval_ref import EvalBlockRef, episode_ref, evaluate_ref   # noqa: E402
+
+
+class EvalAgent:
+    """Learner stub for the evaluation mirrors: a fixed greedy policy, the counters the eval block touches."""
+
+    def __init__(self, a, gain=0.7):
+        self.a, self.gain = a, gain
+        self.timesteps_so_far, self.best_eval_ep_ret, self.rb, self.saved = 0, -float("inf"), [], []
+
+    def predict(self, td, *, explore):
+        assert explore is False
+        return np.tanh(-self.gain * np.asarray(td["observations"], np.float32)[:, : self.a]).astype(np.float32)
+
+    def save(self, path, sfx=None):
+        self.saved.append((self.timesteps_so_far, sfx))
+
+
+def test_episode_with_trajectories_matches_the_restated_reference():
+    o, a = 4, 2
+    gens = [fn(loop.SyntheticVecEnv(o, a, 1, horizon=9, term_at=2.2), EvalAgent(a), 5, need_lists=True) for fn in (loop.episode, episode_ref)]
+    lengths = set()
+    for _ in range(12):
+        got, want = next(gens[0]), next(gens[1])
+        assert set(got) == set(want) == {"observations", "actions", "next_observations", "rewards", "terminations", "dones", "length", "return"}
+        for k in want:
+            assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), k
+        n = int(want["length"])
+        assert all(got[k].shape[0] == n for k in got if k not in ("length", "return"))       # orchestrator.py:450-451
+        assert got["dones"][-1].all() and not got["dones"][:-1].any()
+        lengths.add(n)
+    assert len(lengths) > 1                                       # terminations and time-limit truncations both occurred
+    plain = next(loop.episode(loop.SyntheticVecEnv(o, a, 1, horizon=9, term_at=2.2), EvalAgent(a), 5))
+    assert set(plain) == {"length", "return"}
+
+
+def test_evaluator_matches_the_restated_eval_block():
+    """loop.Evaluator against oracle/eval_ref.py:EvalBlockRef (orchestrator.py:303-305,319-322,354-405) on the same synthetic
+    env and a scripted clock: windowed means (21 calls x 3 episodes overflow the 60-episode window), best-model saves at
+    the same timesteps, speed with burn-in and evaluation time excluded."""
+    o, a = 4, 2
+    cfg = SimpleNamespace(seed=3, eval_steps=3, learning_starts=2, measure_burnin=2, eval_every=4)   # clock starts at the first loop top
+    ticks = {"t": 0.0}
+
+    def clock():
+        ticks["t"] += 0.25
+        return ticks["t"]
+    ag1, ag2 = EvalAgent(a), EvalAgent(a)
+    ev = loop.Evaluator(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=11, term_at=2.0), ag1, clock=clock)
+    ref = EvalBlockRef(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=11, term_at=2.0), ag2, clock)
+    outs = []
+    for side, (obj, ag) in enumerate(((ev, ag1), (ref, ag2))):
+        ticks["t"] = 0.0
+        res = []
+        for it in range(22):
+            ag.gain = 0.7 + 0.05 * it                              # the policy changes: returns move, new bests happen
+            ag.timesteps_so_far += 4
+            ticks["t"] += 1.0                                      # "training" time between evaluations
+            if side == 0:
+                obj.maybe_start_clock(ag.timesteps_so_far)
+                res.append(obj(ag))
+            else:
+                obj.loop_top()
+                res.append(obj.eval_block())
+        outs.append(res)
+    for got, want in zip(*outs):
+        assert got["timestep"] == want["timestep"]
+        assert got["length"] == pytest.approx(want["length"], rel=1e-6) and got["return"] == pytest.approx(want["return"], rel=1e-6)
+        assert ("speed" in got) == ("speed" in want)
+        if "speed" in want:
+            assert got["speed"] == pytest.approx(want["speed"], rel=1e-9)
+    assert ag1.best_eval_ep_ret == pytest.approx(ag2.best_eval_ep_ret, rel=1e-6)
+    assert [h["timestep"] for h in outs[0] if h.get("new_best")] == ref.saved and len(ref.saved) >= 2
+    assert len(ev.ret_buff) == 60                                  # the rolling window is full (20 x eval_steps)
+
+
+def test_evaluate_writes_trajectories_and_means(tmp_path):
+    o, a = 3, 1
+    cfg = SimpleNamespace(seed=9, num_episodes=5, gather_trajectories=True, trajectory_dir=str(tmp_path), load_ckpt=None)
+    tab = loop.Tabular(tmp_path)
+    got = loop.evaluate(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=6, term_at=1.8), EvalAgent(a), "run0", tabular=tab)
+    want, eps = evaluate_ref(cfg, loop.SyntheticVecEnv(o, a, 1, horizon=6, term_at=1.8), EvalAgent(a))
+    assert got["length"] == pytest.approx(want["length"], rel=1e-6) and got["return"] == pytest.approx(want["return"], rel=1e-6)
+    files = sorted((tmp_path / "run0").glob("*.npz"))
+    assert len(files) == 5
+    for f, ep in zip(files, eps):
+        n, r = int(ep["length"]), int(ep["return"])
+        assert f.name == f"{f.name[:3]}_L{n}_R{r}.npz"              # orchestrator.py:452
+        z = np.load(f)
+        for k in ("observations", "actions", "next_observations", "rewards", "terminations", "dones"):
+            assert z[k].shape[0] == n and np.array_equal(z[k], ep[k].astype(z[k].dtype)), k
+            assert z[k].dtype != np.float64                          # float64 columns are stored as float32 (:454-456)
+    import json
+    row = json.loads((tmp_path / "progress.json").read_text().splitlines()[-1])
+    assert row["length"] == pytest.approx(want["length"], rel=1e-6)
