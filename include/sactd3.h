@@ -128,6 +128,13 @@ int sactd3_set_adam_state(sactd3_engine* e, int which, const float* exp_avg, con
 int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* actions, const float* rewards,
                      const float* next_obs, const uint8_t* dones, int n);
 int64_t sactd3_rb_len(const sactd3_engine* e);                             /* len(rb) (orchestrator.py:385) */
+/* layout of one ring record, in floats: out = {record length, offset of s' (= padded width of [s | a]), padded width of s',
+ * rb_capacity}; record = [s (ob_dim) | a (ac_dim) | 0-pad][s' (ob_dim) | 0-pad][r, d (0/1)][0-pad to a 64-byte multiple] */
+int sactd3_rb_layout(const sactd3_engine* e, int32_t out[4]);
+/* rb.extend (orchestrator.py:100-113) with n records ALREADY PACKED (sactd3_rb_layout) IN DEVICE MEMORY: the shared-replay
+ * variant of BASELINE.json's north_star (not in the reference) all-gathers every rank's new rows over RCCL into one device
+ * slab and appends it here with one kernel, no host round trip.  `records` must stay valid until sactd3_sync. */
+int sactd3_rb_extend_device(sactd3_engine* e, const float* records, int n);
 /* rb.sample(batch_size) (orchestrator.py:338): uniform-with-replacement indices from the engine's
  * Philox stream + gather into the engine-owned batch slot. */
 int sactd3_rb_sample(sactd3_engine* e);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sactd3_read_batch", "sactd3_rb_fill_synthetic", "sactd3_set_noise", "sactd3_clear_noise", "sactd3_read_noise",
     "sactd3_update_qnets", "sactd3_update_actor", "sactd3_update_targ_nets", "sactd3_step", "sactd3_predict",
     "sactd3_read_metrics", "sactd3_sync", "sactd3_debug_read", "sactd3_debug_names", "sactd3_graph_kernel_count",
-    "sactd3_time_kernel", "sactd3_time_gather_sweep", "sactd3_time_nodes",
+    "sactd3_time_kernel", "sactd3_time_gather_sweep", "sactd3_time_nodes", "sactd3_rb_layout", "sactd3_rb_extend_device",
 ]
 
 
@@ -82,6 +82,8 @@ def load_library():
         "sactd3_set_adam_state": (C.c_int, [vp, C.c_int, fp, fp, C.c_int64]),
         "sactd3_rb_extend": (C.c_int, [vp, fp, fp, fp, fp, u8p, C.c_int]),
         "sactd3_rb_len": (C.c_int64, [vp]),
+        "sactd3_rb_layout": (C.c_int, [vp, C.POINTER(C.c_int32)]),
+        "sactd3_rb_extend_device": (C.c_int, [vp, C.c_void_p, C.c_int]),
         "sactd3_rb_sample": (C.c_int, [vp]),
         "sactd3_rb_sample_with_indices": (C.c_int, [vp, i64p, C.c_int]),
         "sactd3_load_batch": (C.c_int, [vp, fp, fp, fp, fp, u8p, C.c_int]),

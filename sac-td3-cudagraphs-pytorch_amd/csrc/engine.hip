@@ -1060,6 +1060,40 @@ int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const
   return 0;
 }
 
+int sactd3_rb_layout(const sactd3_engine* e, int32_t out[4]) {
+  if (!e || !out) return SACTD3_EINVAL;
+  out[0] = e->rec_f; out[1] = e->ldc; out[2] = e->ldo; out[3] = e->cfg.rb_capacity;
+  return 0;
+}
+
+// rb.extend with packed records that are already in device memory (shared-replay variant: every rank's rows, all-gathered
+// over RCCL into one device slab): the same k_rb_ingest launch as the host path, reading the slab instead of a pinned slot.
+int sactd3_rb_extend_device(sactd3_engine* e, const float* records, int n) {
+  if (!e || !records || n < 0) return e ? e->fail(SACTD3_EINVAL, "rb_extend_device: bad argument") : SACTD3_EINVAL;
+  USE_DEVICE(e);
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, records) != hipSuccess || at.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return e->fail(SACTD3_EINVAL, "rb_extend_device: `records` is not a device pointer");
+  }
+  const int64_t cap = e->cfg.rb_capacity;
+  int done_rows = 0;
+  while (done_rows < n) {
+    const int chunk = (int)std::min<int64_t>(n - done_rows, cap);
+    IngestArgs g{};
+    g.src = (const float4*)(records + (size_t)done_rows * e->rec_f); g.ring = (float4*)e->ring; g.rec4 = e->rec4; g.n = chunk;
+    g.cursor = (int)e->rb_cursor; g.cap = (int)cap;
+    e->rb_cursor = (e->rb_cursor + chunk) % cap;
+    e->rb_len = std::min<int64_t>(cap, e->rb_len + chunk);
+    g.len_cursor = &e->ctl->rb_len; g.new_len = (int)e->rb_len; g.new_cursor = (int)e->rb_cursor;
+    const int blocks = (int)std::min<long>(1024, ((long)chunk * e->rec4 + 255) / 256);
+    hipLaunchKernelGGL(k_rb_ingest, dim3(std::max(blocks, 1)), dim3(256), 0, e->stream, g);
+    HIPCHK(hipGetLastError());
+    done_rows += chunk;
+  }
+  return 0;
+}
+
 int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EINVAL; }
 
 int sactd3_rb_sample(sactd3_engine* e) {

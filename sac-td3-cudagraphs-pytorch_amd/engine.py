@@ -167,6 +167,26 @@ class Engine:
         self._ck(self.lib.sactd3_rb_extend(self._h, _fp(obs), _fp(act), _fp(rew), _fp(nobs),
                                            done.ctypes.data_as(C.POINTER(C.c_uint8)), n))
 
+    def rb_layout(self) -> Dict[str, int]:
+        out = (C.c_int32 * 4)()
+        self._ck(self.lib.sactd3_rb_layout(self._h, out))
+        return dict(record_floats=int(out[0]), next_obs_offset=int(out[1]), next_obs_width=int(out[2]), capacity=int(out[3]))
+
+    def pack_records(self, obs, act, rew, nobs, done) -> np.ndarray:
+        """[n, record_floats] float32 in the ring's record layout (include/sactd3.h: sactd3_rb_layout)."""
+        obs, act, rew, nobs, done, n = self._rows(obs, act, rew, nobs, done)
+        lay, o, a = self.rb_layout(), self.cfg.ob_dim, self.cfg.ac_dim
+        rec = np.zeros((n, lay["record_floats"]), np.float32)
+        rec[:, :o], rec[:, o:o + a] = obs, act
+        rec[:, lay["next_obs_offset"]:lay["next_obs_offset"] + o] = nobs
+        tail = lay["next_obs_offset"] + lay["next_obs_width"]
+        rec[:, tail], rec[:, tail + 1] = rew, done.astype(np.float32)
+        return rec
+
+    def rb_extend_device(self, device_ptr: int, n: int) -> None:
+        """append n packed records that already live in device memory (kept alive by the caller until sync())."""
+        self._ck(self.lib.sactd3_rb_extend_device(self._h, C.c_void_p(int(device_ptr)), int(n)))
+
     def rb_len(self) -> int:
         return int(self._ck(self.lib.sactd3_rb_len(self._h)))
 

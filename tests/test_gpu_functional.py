@@ -186,3 +186,62 @@ def test_load_refuses_a_resume_blob_of_another_shape(tmp_path):
     assert np.array_equal(agent.engine.get_params(_lib.CRITICS), before)        # nothing was written
     with pytest.raises(ValueError):
         agent.engine.set_adam_state(_lib.CRITICS, np.zeros(5, np.float32), np.zeros(5, np.float32), 1)
+
+
+def test_shared_replay_device_path_equals_the_host_path():
+    """launcher.SharedReplay on its device path (rows packed into the ring's record layout, one device slab, one k_rb_ingest
+    reading device memory -- what every rank does after the RCCL all-gather) leaves the ring bit-identical to rb.extend on the
+    host path, including the wrap-around; single rank here, the 2-rank exchange itself is covered over gloo on CPU."""
+    from sac_td3_cudagraphs_pytorch_amd import launcher
+    o, a, cap, B = 17, 6, 700, 64
+    rows = dict(observations=torch.randn(1000, o), actions=torch.rand(1000, a) * 2 - 1, rewards=torch.randn(1000, 1),
+                next_observations=torch.randn(1000, o), dones=torch.rand(1000, 1) < 0.1)
+    rows["terminations"] = rows["dones"]
+    rings = []
+    for device_path in (True, False):
+        eng = P.Engine(P.Config(ob_dim=o, ac_dim=a, batch_size=B, rb_capacity=cap, max_envs=4), [-1] * a, [1] * a)
+        rb = P.ReplayBuffer(cap)
+        rb._bind(eng)
+        shared = launcher.SharedReplay(None, rb, device=torch.device("cuda:0"), every=3, force_device_path=device_path)
+        assert (shared._engine is not None) == device_path
+        for t in range(0, 1000, 4):                                  # 250 env steps of 4 envs: wraps the 700-row ring
+            shared.extend({k: v[t:t + 4] for k, v in rows.items()})
+        shared.flush()
+        assert len(shared) == cap
+        got = []
+        for lo in range(0, cap - B + 1, B):
+            eng.rb_sample_with_indices(np.arange(lo, lo + B))
+            got.append(eng.read_batch())
+        rings.append(got)
+    for x, y in zip(*rings):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    lay = eng.rb_layout()
+    assert lay["record_floats"] % 16 == 0 and lay["capacity"] == cap and lay["next_obs_offset"] >= o + a
+    with pytest.raises(P.EngineError):
+        eng.rb_extend_device(0, 4)                                   # a null / host pointer is refused, not dereferenced
+
+
+def test_sweep_launcher_trains_on_the_gpu(tmp_path):
+    """The sweep runner for real: 2 seeds of the `debug` bundle (Hopper-v4 shapes, synthetic env), 2 worker processes (both on
+    device 0 here), each job = loop.train with evaluation, tabular files, best checkpoint and a summary."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-m", "sac_td3_cudagraphs_pytorch_amd.launcher", "--env_bundle", "debug", "--num_seeds", "2",
+                          "--gpus", "2", "--device", "0", "--num_timesteps", "3000", "--learning_starts", "500", "--eval_every", "1000",
+                          "--eval_steps", "2", "--batch_size", "64", "--rb_capacity", "10000", "--out", str(tmp_path)],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    jobs = [json.loads(ln[4:]) for ln in out.stdout.splitlines() if ln.startswith("JOB ")]
+    assert sorted(j["seed"] for j in jobs) == [0, 1] and {j["gpu"] for j in jobs} == {0}
+    for j in jobs:
+        assert j["timesteps"] == 3004 and j["gradient_steps"] == 626 and j["actor_updates"] > 400     # orchestrator.py:317-352 counters
+        assert all(np.isfinite(v) for v in j["final_metrics"].values()) and np.isfinite(j["best_eval_return"])
+        files = set(os.listdir(j["dir"]))
+        assert {"progress.json", "progress.csv", "summary.json", "ckpt_best.pth"} <= files
+    sweep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("SWEEP ")][0][6:])
+    assert sweep["jobs"] == 2 and sweep["gradient_steps"] == 2 * 626

@@ -115,3 +115,21 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["dry_run"] is True and d["value"] is None
     assert d["config"]["parallelism"].startswith("2 independent seeds")
+
+
+def test_sweep_launcher_starts_one_worker_per_gpu_and_shards_the_jobs(tmp_path):
+    """python -m sac_td3_cudagraphs_pytorch_amd.launcher: (env bundle x seeds) -> one worker process per GPU, job k on worker
+    k mod N (spawner.py:147-178,291,313-349 semantics on one node).  --dry-run: the workers are real processes, nothing runs
+    on a GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-m", "sac_td3_cudagraphs_pytorch_amd.launcher", "--env_bundle", "low", "--num_seeds", "3",
+                          "--gpus", "4", "--dry-run", "--out", str(tmp_path)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    jobs = [json.loads(ln[4:]) for ln in out.stdout.splitlines() if ln.startswith("JOB ")]
+    sweep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("SWEEP ")][0][6:])
+    assert sweep["jobs"] == sweep["expected_jobs"] == 6 and sweep["gpus"] == 4
+    want = launcher.sweep_jobs("low", 3)
+    assert sorted((j["env_id"], j["seed"]) for j in jobs) == sorted(want)
+    for j in jobs:
+        assert j["gpu"] == want.index((j["env_id"], j["seed"])) % 4
