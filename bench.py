@@ -39,8 +39,8 @@ DELAY = 2                 # actor_update_delay (sac.yml:44, td3.yml): actor upda
 
 def describe(w):
     return (f"{'TD3' if w['td3'] else 'SAC'} {w['env']} batch={w['batch']}, 2x256 MLP + LayerNorm, {w['rows']} rows resident in a "
-            f"{w['capacity']}-row HBM replay ring, one hipGraph launch per iteration (1 critic update, 2 actor"
-            f"{'' if w['td3'] else '+alpha'} updates every 3rd, Polyak)")
+            f"{w['capacity']}-row HBM replay ring, per iteration 1 critic update + Polyak and every 3rd iteration 2 actor"
+            f"{'' if w['td3'] else '+alpha'} updates; one hipGraph launch per 3-iteration schedule period")
 
 
 def gather_algo_bytes(o, a, batch):
@@ -67,6 +67,10 @@ def make_engine(w, seed, device_id, rows=None, capacity=None):
 
 
 def run_steps(eng, it, n):
+    """n loop iterations from iteration number `it` on: whole periods of the actor schedule (1 iteration with the actor updates
+    + DELAY critic-only ones) go out as ONE graph launch (sactd3_step_period), iterations outside a whole period one by one."""
+    if hasattr(eng, "run_iterations") and os.environ.get("SACTD3_BENCH_PERIOD", "1") != "0":
+        return eng.run_iterations(it, n)
     for _ in range(n):
         eng.step(it % (DELAY + 1) == 0)
         it += 1
@@ -291,6 +295,17 @@ def node_budget(w, workload, device_id, ms_per_step, iters=200):
                     "DIFFERENT kernels and the gap between graph replays add or save"}, rooflines
 
 
+def kernel_counts(eng):
+    """kernel nodes: of the 3-iteration period graph the timed loop replays, and per kind of iteration (their sum = the period)"""
+    per = eng.graph_kernel_count(4)
+    if not eng.graph_kernel_count(2):     # (after the timed region) instantiate the single-iteration graphs to count their nodes
+        eng.step(False)
+    if not eng.graph_kernel_count(3):
+        eng.step(True)
+    c0, c1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
+    return {"period_of_3_iterations": per, "critic_only": c0, "critic_plus_2_actor": c1, "average_per_iteration": per / (DELAY + 1) if per else None}
+
+
 def gather_cold(eng, w, iters=300):
     """the replay gather at the workload's own batch size with a fresh index draw per launch (rows from HBM / MALL, not L2)."""
     us = eng.time_kernel("gather", iters)
@@ -336,7 +351,7 @@ def secondary_config(name, device_id, steps=3000, warmup=300):
     eng.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"workload": describe(w), "value": steps / dt, "unit": "gradient-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
-           "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
+           "kernels_per_iteration": kernel_counts(eng),
            "final_metrics": eng.read_metrics(), "replay_gather_cold": gather_cold(eng, w)}
     eng.close()
     out["node_us"], rl = node_budget(w, name, device_id, out["ms_per_step"])
@@ -379,6 +394,11 @@ class _DryEngine:
 
     def graph_kernel_count(self, which):
         return 0
+
+    def run_iterations(self, i0, n):
+        for _ in range(n):
+            self.step(False)
+        return i0 + n
 
     def close(self):
         pass
@@ -459,7 +479,7 @@ def main():
             "config": {"workload": describe(w), "parallelism": f"{world} independent seeds, one per GPU, no collective"},
             # one iteration = 1 critic update (+ Polyak) and, every 3rd iteration, 2 actor(+alpha) updates
             "critic_updates_per_s": world * args.steps / dt, "actor_updates_per_s": world * args.steps / dt * 2.0 / 3.0,
-            "kernels_per_iteration": {"critic_only": eng.graph_kernel_count(2), "critic_plus_2_actor": eng.graph_kernel_count(3)},
+            "kernels_per_iteration": kernel_counts(eng),
             "final_metrics": metrics,
         }
         if args.dry_run_ranks:

@@ -164,6 +164,10 @@ int sactd3_update_targ_nets(sactd3_engine* e, int64_t qnet_updates_so_far);
  * update, (if do_actor) actor_update_delay x actor(+alpha) updates on the same batch, Polyak
  * (subject to crit_targ_update_freq and the engine's own update counter). */
 int sactd3_step(sactd3_engine* e, int do_actor);
+/* actor_update_delay + 1 consecutive iterations of orchestrator.py:337-352 -- the first with the actor updates, the others
+ * critic-only: one period of the schedule of :345-349 -- as ONE graph launch.  Equal to that many sactd3_step calls, bit for
+ * bit.  Needs TD3 or crit_targ_update_freq == 1 (else SACTD3_ESTATE: issue the iterations with sactd3_step). */
+int sactd3_step_period(sactd3_engine* e);
 /* Agent.predict (agents/agent.py:172-181): obs [n, ob_dim] host -> actions [n, ac_dim] host. [sync] */
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions);
 
@@ -175,7 +179,7 @@ int sactd3_sync(sactd3_engine* e);                                          /* [
  * With dst == NULL only the size is returned. Names: see sactd3_debug_names(). [sync] */
 int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_t max_floats);
 const char* sactd3_debug_names(void);
-/* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1) */
+/* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1), 4 step_period */
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph);
 /* average device time in microseconds of `iters` back-to-back launches of one kernel of the path,
  * measured with hipEvents on the engine's stream: "gather" (a fresh index draw per launch), "polyak", "trunk_critics" (the 4-net

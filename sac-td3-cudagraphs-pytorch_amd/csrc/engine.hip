@@ -73,7 +73,7 @@ static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst)
 }
 
 static const int BIG_BATCH = 1024;   // from here on the hidden layers run as 64 x 64-tiled GEMMs + a LayerNorm row kernel
-enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_COUNT = 6 };
+enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_PERIOD = 6, G_COUNT = 7 };
 static const int NSTAGE = 32;
 
 struct NodeInfo { std::string name; double flops; double bytes; long threads; };
@@ -1232,6 +1232,24 @@ int sactd3_step(sactd3_engine* e, int do_actor) {
   return run_graph(e, which, [&](hipStream_t s) { return enqueue_step(e, s, act, polyak); });
 }
 
+// One period of the actor schedule (orchestrator.py:345-349: iteration i with i % (delay + 1) == 0 runs the actor updates,
+// the next `delay` iterations are critic-only) as ONE graph launch: delay + 1 iterations back to back, no host call and no
+// inter-replay gap in between.  Only when every iteration takes the same target-update branch (TD3, or crit_targ_update_freq
+// == 1); otherwise the caller gets SACTD3_ESTATE and issues the iterations one by one.
+int sactd3_step_period(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step_period: buffer is empty");
+  const bool td3 = e->cfg.prefer_td3_over_sac;
+  if (!td3 && e->cfg.crit_targ_update_freq != 1) return e->fail(SACTD3_ESTATE, "step_period: needs crit_targ_update_freq == 1");
+  const int n = e->cfg.actor_update_delay + 1;
+  e->qnet_updates += n;
+  return run_graph(e, G_PERIOD, [&](hipStream_t s) {
+    for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true));
+    return 0;
+  });
+}
+
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions) {
   if (!e || !obs || !actions) return SACTD3_EINVAL;
   USE_DEVICE(e);
@@ -1321,10 +1339,10 @@ int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_
 
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
   if (!e) return SACTD3_EINVAL;
-  static const int map[4] = {G_Q, G_A, G_STEP01, G_STEP11};
-  if (which_graph < 0 || which_graph > 3) return SACTD3_EINVAL;
+  static const int map[5] = {G_Q, G_A, G_STEP01, G_STEP11, G_PERIOD};
+  if (which_graph < 0 || which_graph > 4) return SACTD3_EINVAL;
   int w = map[which_graph];
-  if (!e->graphs[w] && which_graph >= 2) w -= 1;   // the no-Polyak variant, if that is the one in use
+  if (!e->graphs[w] && (which_graph == 2 || which_graph == 3)) w -= 1;   // the no-Polyak variant, if that is the one in use
   return e->graph_nodes[w];
 }
 

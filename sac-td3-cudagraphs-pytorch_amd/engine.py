@@ -244,6 +244,25 @@ class Engine:
     def step(self, do_actor: bool) -> None:
         self._ck(self.lib.sactd3_step(self._h, int(bool(do_actor))))
 
+    def step_period(self) -> None:
+        """actor_update_delay + 1 iterations (actor updates in the first) as one graph launch."""
+        self._ck(self.lib.sactd3_step_period(self._h))
+
+    def run_iterations(self, i0: int, n: int) -> int:
+        """iterations i0 .. i0 + n - 1 of the loop (orchestrator.py:337-352 schedule: actor updates when i % (delay + 1) == 0),
+        whole periods as one graph launch each, the rest one by one.  Returns i0 + n."""
+        period = self.cfg.actor_update_delay + 1
+        can = self.cfg.actor_update_delay > 0 and (self.cfg.prefer_td3_over_sac or self.cfg.crit_targ_update_freq == 1)
+        i, end = i0, i0 + n
+        while i < end:
+            if can and i % period == 0 and i + period <= end:
+                self.step_period()
+                i += period
+            else:
+                self.step(i % period == 0)
+                i += 1
+        return i
+
     def predict(self, obs, explore: bool) -> np.ndarray:
         obs = _f32(obs).reshape(-1, self.cfg.ob_dim)
         out = np.empty((obs.shape[0], self.cfg.ac_dim), np.float32)

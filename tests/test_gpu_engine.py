@@ -458,6 +458,34 @@ def test_fused_step_equals_api_sequence(algo, env, B):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024), ("sac", "hopper", 64)])
+def test_period_graph_equals_single_iterations(algo, env, B):
+    """sactd3_step_period (3 iterations of the schedule of orchestrator.py:345-349 in ONE graph: actor updates in the first,
+    then two critic-only ones) == three sactd3_step calls, bit for bit; Engine.run_iterations mixes both forms around period
+    boundaries; with crit_targ_update_freq != 1 (SAC) the period form is refused and run_iterations falls back."""
+    res = []
+    for mode in ("period", "single"):
+        ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=4)
+        eng.rb_extend(*[t.numpy() for t in synth_transitions(3000, o, a, bound, seed=23)])
+        if mode == "period":
+            assert eng.run_iterations(1, 10) == 11          # iterations 1, 2 singly, periods 3-5 and 6-8, then 9, 10
+            assert eng.graph_kernel_count(4) == eng.graph_kernel_count(2) * 2 + eng.graph_kernel_count(3)
+        else:
+            for i in range(1, 11):
+                eng.step(i % 3 == 0)
+        res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR_TARGET),
+                    eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"], eng.get_adam_state(_lib.CRITICS)[2], eng.get_adam_state(_lib.ACTOR)[2]))
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    assert res[0][6] == 10 and res[0][7] == 6
+    if algo == "sac":
+        ref, eng, (o, a, bound) = make_pair(algo, env, 32, crit_targ_update_freq=2)
+        eng.rb_fill_synthetic(500)
+        with pytest.raises(P.EngineError):
+            eng.step_period()
+        assert eng.run_iterations(0, 7) == 7 and eng.get_adam_state(_lib.CRITICS)[2] == 7
+
+
 def test_native_noise_stream_matches_philox_oracle():
     ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256, seed=77)
     obs, act, rew, nobs, done = synth_transitions(256, o, a, bound, seed=1)
