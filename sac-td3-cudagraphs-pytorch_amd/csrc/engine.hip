@@ -259,7 +259,8 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     if (e->tune_nt == 1) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
-    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0)), 1, (unsigned)nets);
+    const int nzb = fuse1 ? (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0) : 0;
+    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0) + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
     if (e->node_log) {
       const int c1 = (g.K1 + 15) / 16;
@@ -384,7 +385,8 @@ static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] 
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
 struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
 struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false;
-                    const AlphaArgs* alpha = nullptr; };   // alpha: a pending temperature step to carry as one extra block
+                    const AlphaArgs* alpha = nullptr;      // alpha: a pending temperature step to carry as one extra block
+                    int nnoise = 0; NoiseJob noise[2] = {}; bool* noise_taken = nullptr; };   // the following tail's draws (see NoiseJob)
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
@@ -435,6 +437,11 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.adam_pw = tk.adam_pw; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
     h.w1_magic = magic_div((unsigned)L.ld1, 4u * HID * (unsigned)L.ld1);
     if (tk.alpha) { h.alpha_block = 1; h.al = *tk.alpha; }
+    if (tk.nnoise > 0) {   // the draws of the tail that follows ride in this launch as a few extra blocks
+      h.nz_n = tk.nnoise; h.nz_ctl = e->ctl;
+      for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
+      if (tk.noise_taken) *tk.noise_taken = true;
+    }
     if (tk.fuse_gather) {   // x = the s' field of the sampled records; extra blocks fill the batch slot (see NtArgs)
       h.ring_rows = 1; h.ring_off = e->ldc; h.ga = gather_args(e, e->ring, -1);
       h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
@@ -469,8 +476,22 @@ static ActorTail tail_args(sactd3_engine* e, const float* z2, const float* P, in
   t.td3_std = e->cfg.td3_std; t.td3_c = e->cfg.td3_c; t.noise_std = e->cfg.actor_noise_std;
   return t;
 }
+static NoiseJob noise_job(sactd3_engine* e, int site_buf, unsigned site_code, int ctr_add, int rows) {
+  NoiseJob z{};
+  z.eps = e->eps[site_buf]; z.ctr = site_buf == SACTD3_SITE_PREDICT ? &e->ctl->predict_ctr : &e->ctl->noise_ctr;
+  z.ctr_add = ctr_add; z.site_code = site_code; z.site_buf = site_buf; z.n = rows * e->a;
+  return z;
+}
+// rows of the batch one block of the actor-tail kernel handles (narrow heads: one wave per 4 rows, see k_actor_tail_s)
+static int tail_rows_per_block(const ActorTail& t) { return (t.L.nh <= 8 && t.a <= 8) ? 4 : 16; }
 static int launch_tail(sactd3_engine* e, hipStream_t s, const ActorTail& t) {
   const int nh = t.L.nh;
+  if (tail_rows_per_block(t) == 4) {
+    LAUNCH("k_actor_tail_s<4>", 2.0 * t.B * (double)HID * nh,
+           4.0 * ((double)t.B * HID * (t.train ? 3 : 1) + (double)nh * (HID + 1) + 2.0 * HID + (double)t.B * (3 * t.a + 2) + (t.obs_src ? 2.0 * t.B * t.o : 0.0)),
+           k_actor_tail_s<4>, dim3((t.B + 3) / 4), dim3(64), t);
+    return 0;
+  }
   LAUNCH("k_actor_tail", 2.0 * t.B * (double)HID * nh,
          4.0 * ((double)t.B * HID * (t.train ? 3 : 1) + (double)nh * (HID + 1) + 2.0 * HID + (double)t.B * (3 * t.a + 2) + (t.obs_src ? 2.0 * t.B * t.o : 0.0)),
          k_actor_tail, dim3((t.B + 15) / 16), dim3(256), t);
@@ -511,9 +532,12 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
     tk.fuse_gather = in_kernel_gather;
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
+    bool eps_ready = false;
+    if (!td3 || mode == 1) { tk.nnoise = 1; tk.noise[0] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise_taken = &eps_ready; }
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
     ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
+    t.eps_ready = eps_ready;
     if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
     RCCHK(launch_tail(e, s, t));
   }
@@ -578,9 +602,13 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   e->node_role = (j & 1) ? "actor1/policy" : "actor0/policy";
   if (!head_done) {  // a_pi, logp = pi(s) with stores for the backward pass
     const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
+    TrunkTicks tk{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr};
+    bool eps_ready = false;
+    if (!td3) { tk.nnoise = 1; tk.noise[0] = noise_job(e, sb_a, 16u, 0, B); tk.noise_taken = &eps_ready; }
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
     ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
     t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
+    t.eps_ready = eps_ready;
     RCCHK(launch_tail(e, s, t));
   }
   e->node_role = (j & 1) ? "actor1/q(s,pi)" : "actor0/q(s,pi)";
@@ -665,16 +693,24 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
       // stores and Adam tick) and one tail launch with two draws.  Streams: temperature (ctr, 32), policy (ctr + 1, 16),
       // exactly what the two separate launches would consume.
       const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
-      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr}));
       const int sb_a_next = SACTD3_SITE_ACTOR0 + ((j + 1) & 1);
+      TrunkTicks tk{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr};
+      bool eps_ready = false;
+      tk.nnoise = 2; tk.noise[0] = noise_job(e, sb_a_next, 16u, 1, B); tk.noise[1] = noise_job(e, sb_l, 32u, 0, B); tk.noise_taken = &eps_ready;
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a_next, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
       t.obs_src = e->X; t.lds = e->ldc; t.ctr_add = 1;
       t.dual = 1; t.site_buf2 = sb_l; t.site_code2 = 32u; t.eps2 = e->eps[sb_l]; t.logp2 = e->logp_al;
+      t.eps_ready = eps_ready;
       RCCHK(launch_tail(e, s, t));
     } else if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
       const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
-      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
+      TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+      bool eps_ready = false;
+      tk.nnoise = 1; tk.noise[0] = noise_job(e, sb_l, 32u, 0, B); tk.noise_taken = &eps_ready;
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
+      t.eps_ready = eps_ready;
       RCCHK(launch_tail(e, s, t));
     }
     AlphaArgs al{};
@@ -1260,17 +1296,21 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
     memset(e->h_obs + (size_t)i * e->ldo, 0, sizeof(float) * e->ldo);
     memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
   }
+  bool eps_ready = false;
   // The kernels read the observations from, and write the actions to, the pinned host buffers themselves (a few hundred
   // bytes over the host link): two kernels and one synchronisation per call, no copy commands, no separate counter kernel.
   {
     const TrunkGrp g{e->h_obs, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
-    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
+    TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+    if (explore) { tk.nnoise = 1; tk.noise[0] = noise_job(e, SACTD3_SITE_PREDICT, 48u, 0, n); tk.noise_taken = &eps_ready; }
+    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, tk));
   }
   const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
   ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr);
+  t.eps_ready = eps_ready;
   // the tail reads predict_ctr (its noise stream) and may only advance it itself when it is a single block: with more
   // rows than one block holds, a late block could read the counter after block 0 has bumped it
-  const bool one_block = n <= 16;
+  const bool one_block = n <= tail_rows_per_block(t);
   if (explore && one_block) t.tick = &e->ctl->predict_ctr;
   RCCHK(launch_tail(e, e->stream, t));
   if (explore && !one_block) {
@@ -1408,16 +1448,25 @@ int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, 
   }
   hipEvent_t t0, t1;
   HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+  // clocks up before anything is timed (an engine is usually created just before this call: the GPU has been idle), then
+  // every node in 3 batches of `iters` launches, the fastest batch counting (a batch hit by a clock ramp or by another
+  // process's work on the card would otherwise show up as a 100x outlier)
+  e->node_only = -1;
+  for (int i = 0; i < 60 && rc == 0; ++i) rc = seq();
   for (int k = 0; k < n && rc == 0; ++k) {
     e->node_only = k;
     for (int i = 0; i < 3 && rc == 0; ++i) rc = seq();
-    hipEventRecord(t0, e->stream);
-    for (int i = 0; i < iters && rc == 0; ++i) rc = seq();
-    hipEventRecord(t1, e->stream);
-    if (hipEventSynchronize(t1) != hipSuccess) rc = e->fail(SACTD3_EHIP, "time_nodes: hipEventSynchronize");
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, t0, t1);
-    usec[k] = ms * 1000.f / (float)iters;
+    float best = 0.f;
+    for (int rep = 0; rep < 3 && rc == 0; ++rep) {
+      hipEventRecord(t0, e->stream);
+      for (int i = 0; i < iters && rc == 0; ++i) rc = seq();
+      hipEventRecord(t1, e->stream);
+      if (hipEventSynchronize(t1) != hipSuccess) rc = e->fail(SACTD3_EHIP, "time_nodes: hipEventSynchronize");
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, t0, t1);
+      if (rep == 0 || ms < best) best = ms;
+    }
+    usec[k] = best * 1000.f / (float)iters;
     if (flops) flops[k] = log[k].flops;
     if (bytes) bytes[k] = log[k].bytes;
     if (threads) threads[k] = log[k].threads;

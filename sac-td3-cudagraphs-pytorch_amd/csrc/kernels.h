@@ -182,6 +182,32 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
   return (k & 1u) ? rad * __builtin_amdgcn_sinf(u2) : rad * __builtin_amdgcn_cosf(u2);
 }
 
+// all four normals of Philox block q (elements 4q .. 4q + 3): identical to philox_normal(seed, ctr, site, 4q + k), k = 0..3
+__device__ __forceinline__ float4 philox_normal4(unsigned long long seed, unsigned ctr, unsigned site, unsigned q) {
+  const Philox4 r = philox4x32_10(ctr, 0u, SACTD3_STREAM_NOISE + site, q, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float ua = philox_u01(r.v[0]), ub = philox_u01(r.v[1]), uc = philox_u01(r.v[2]), ud = philox_u01(r.v[3]);
+  const float r0 = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(ua));
+  const float r1 = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(uc));
+  return make_float4(r0 * __builtin_amdgcn_cosf(ub), r0 * __builtin_amdgcn_sinf(ub), r1 * __builtin_amdgcn_cosf(ud), r1 * __builtin_amdgcn_sinf(ud));
+}
+// The N(0,1) draws of one noise site, produced AHEAD of the kernel that consumes them: the actor tail sits on the critical
+// path and Philox + Box-Muller is ~1500 cycles behind its first memory round trip (the stream counter), while the trunk
+// launch in front of it has idle CUs -- a few extra blocks of that launch fill the site's eps buffer (unless the caller
+// injected values there), and the tail just loads them like injected ones.
+struct NoiseJob { float* eps; const int* ctr; int ctr_add; unsigned site_code; int site_buf; int n; int blocks; };
+__device__ __forceinline__ void noise_body(const NoiseJob& z, const DevCtl* ctl, unsigned local_block) {
+  const int inject = ctl->inject_eps[z.site_buf], ctr = *z.ctr;
+  const unsigned long long seed = ctl->seed;
+  const unsigned q = local_block * 256u + threadIdx.x;
+  if (inject || 4 * q >= (unsigned)z.n) return;
+  const float4 v = philox_normal4(seed, (unsigned)(ctr + z.ctr_add), z.site_code, q);
+  float* d = z.eps + 4 * (long)q;
+  d[0] = v.x;
+  if (4 * q + 1 < (unsigned)z.n) d[1] = v.y;
+  if (4 * q + 2 < (unsigned)z.n) d[2] = v.z;
+  if (4 * q + 3 < (unsigned)z.n) d[3] = v.w;
+}
+
 // ---- row-owner layout: thread (row = t >> 4, sub = t & 15) holds v[q] = columns 4*sub + 64*q .. +3, q = 0..3
 struct Row16 { float4 v[4]; };
 __device__ __forceinline__ Row16 row_ld(const float* row, int sub) {
@@ -434,6 +460,8 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // One more block (after the gather blocks, net 0 only) can carry the temperature step of the PREVIOUS actor update
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
+  // ... and the noise draws of the actor tail that follows this launch (see NoiseJob): nz_n jobs, nz[i].blocks blocks each
+  int nz_n; NoiseJob nz[2]; const DevCtl* nz_ctl;
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -466,9 +494,13 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
-  if (FUSE1 && (p.gblocks || p.alpha_block) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step
-    if ((int)blockIdx.x < p.nt_blocks + p.gblocks) gather_body(p.ga, blockIdx.x - p.nt_blocks);
-    else if (blockIdx.z == 0) alpha_body(p.al);
+  if (FUSE1 && (p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
+    const int x = (int)blockIdx.x - p.nt_blocks;
+    if (x < p.gblocks) gather_body(p.ga, x);
+    else if (blockIdx.z != 0) { }
+    else if (x < p.gblocks + p.alpha_block) alpha_body(p.al);
+    else if (x < p.gblocks + p.alpha_block + p.nz[0].blocks) noise_body(p.nz[0], p.nz_ctl, x - p.gblocks - p.alpha_block);
+    else if (p.nz_n > 1) noise_body(p.nz[1], p.nz_ctl, x - p.gblocks - p.alpha_block - p.nz[0].blocks);
     return;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
@@ -1434,6 +1466,7 @@ struct ActorTail {
   // SAC, dual mode: a SECOND, gradient-free draw through the same head outputs (the temperature step's fresh sample,
   // agents/agent.py:297-299) sharing this kernel with the next actor update's sample: only its log-prob is kept
   int dual; int site_buf2; unsigned site_code2; float* eps2; float* logp2;
+  int eps_ready;                         // the eps buffers were filled by the preceding trunk launch's noise blocks: load, draw nothing
 };
 
 // the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
@@ -1442,7 +1475,7 @@ struct ActorTail {
 // must not be read from memory a second time
 __device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr,
                                            int bc, int b, int j, bool valid) {
-  if (p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
+  if (p.eps_ready || p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
   const float e = philox_normal(p.ctl->seed, (unsigned)ctr, site_code, (unsigned)(bc * p.a + j));
   if (valid) eps[(long)b * p.a + j] = e;
   return e;
@@ -1471,7 +1504,8 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   int tick_v = 0;
   if (ticker) tick_v = *p.tick;
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
-  const int inj1 = need_eps ? p.ctl->inject_eps[p.site_buf] : 0, inj2 = p.dual ? p.ctl->inject_eps[p.site_buf2] : 0;
+  // (eps_ready: the buffers already hold this launch's draws -- treated like injected ones)
+  const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
   const unsigned long long seed = p.ctl->seed;
   const int ctr = *p.ctr;
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
@@ -1507,8 +1541,9 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     obt = srow[min(4 * o4 + sub, p.o - 1)];
   }
   // native draws (no memory involved)
-  const float e_nat1 = need_eps ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
-  const float e_nat2 = p.dual ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej) : 0.f;
+  const bool gen = !p.eps_ready;                 // (uniform)
+  const float e_nat1 = (gen && need_eps) ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
+  const float e_nat2 = (gen && p.dual) ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej) : 0.f;
   STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
@@ -1634,6 +1669,142 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   }
   if (ticker) *p.tick = tick_v + 1;
   STAMP(5);
+}
+
+// Narrow heads (nh <= 8: Hopper's SAC head 2 x 3, HalfCheetah's TD3 head 6 ...).  The general kernel above spends two block
+// barriers, an LDS round trip each way and an MFMA tile on a [16 x 256] x [256 x 6] product; here a row lives in ONE wave
+// (RPB rows x 16 threads = 64 threads per block, so 4x as many blocks), the head is nh dot products reduced with DPP, and there
+// is no LDS, no barrier and no MFMA at all.  Same arithmetic per element as k_actor_tail (the dot products' summation order
+// differs, inside the 1e-5 budget of north_star); dual draws, training stores, the [s | pi(s)] row build and the counter
+// tick behave identically.
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s(ActorTail p) {
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15;
+  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
+  const int nh = p.L.nh;                         // <= 8, and a <= 8
+  const float* Wh = p.P + p.L.Wh;
+  const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
+  int tick_v = 0;
+  if (ticker) tick_v = *p.tick;
+  const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
+  const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
+  const unsigned long long seed = p.ctl->seed;
+  const int ctr = *p.ctr;
+  const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
+  const Row16 g = row_ld(p.P + (p.ln ? p.L.g2 : 0), sub), be = row_ld(p.P + (p.ln ? p.L.be2 : 0), sub);
+  Row16 w[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) w[n] = row_ld(Wh + (long)min(n, nh - 1) * HID, sub);   // unconditional, row clamped
+  const int j0 = min(sub, p.a - 1);
+  const long ej = (long)bc * p.a + j0;
+  float e_bh0 = p.P[p.L.bh + j0], e_bh1 = p.sac ? p.P[p.L.bh + p.a + j0] : 0.f;
+  float e_sc = p.scale[j0], e_bi = p.bias[j0];
+  const bool smooth = !p.sac && p.mode == 1;
+  float e_lo = 0.f, e_hi = 0.f;
+  if (smooth) { e_lo = p.min_ac[j0]; e_hi = p.max_ac[j0]; }
+  float e_in1 = 0.f, e_in2 = 0.f;
+  if (need_eps) e_in1 = p.eps[ej];
+  if (p.dual) e_in2 = p.eps2[ej];
+  const int o4 = p.o >> 2, orem = p.o & 3;
+  float4 ob4[2] = {f4(0.f), f4(0.f)};
+  float obt = 0.f;
+  if (p.obs_src) {
+    const float* srow = p.obs_src + (long)bc * p.lds;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ob4[i] = ld4(srow + 4 * min(sub + 16 * i, max(o4 - 1, 0)));
+    obt = srow[min(4 * o4 + sub, p.o - 1)];
+  }
+  const bool gen = !p.eps_ready;
+  const float e_nat1 = (gen && need_eps) ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
+  const float e_nat2 = (gen && p.dual) ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej) : 0.f;
+  Row16 xh, y; float rstd;
+  ln_fwd(z, g, be, p.ln, xh, y, rstd);
+  Row16 h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  // head: every lane of the row gets all nh outputs; lane `sub` keeps output sub (and a + sub for the SAC log-std half)
+  float u0 = 0.f, u1 = 0.f;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    row_pin(w[n]);
+    const float tot = row16_sum(row_dot(h, w[n]));
+    if (n < nh) { u0 = (n == sub) ? tot : u0; u1 = (n == p.a + sub) ? tot : u1; }
+  }
+  PIN(e_bh0); PIN(e_bh1); PIN(e_sc); PIN(e_bi); PIN(e_lo); PIN(e_hi); PIN(e_in1); PIN(e_in2); PIN(tick_v);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
+  PIN(obt);
+  const float e = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
+  const float e2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
+  if (valid) {
+    if (p.train) {
+      row_st(p.h2 + (long)b * HID, sub, h);
+      row_st(p.xh2 + (long)b * HID, sub, xh);
+      if (sub == 0) p.rstd2[b] = rstd;
+    }
+    if (sub < p.a) {
+      if (need_eps && !inj1) p.eps[ej] = e_nat1;
+      if (p.dual && !inj2) p.eps2[ej] = e_nat2;
+    }
+    if (p.obs_src) {
+      const float* __restrict__ src = p.obs_src + (long)b * p.lds;
+      float* __restrict__ dst = p.dst + (long)b * p.ldd;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (sub + 16 * i < o4) st4(dst + 4 * (sub + 16 * i), ob4[i]);
+      if (sub < orem) dst[4 * o4 + sub] = obt;
+      for (int c = sub + 32; c < o4; c += 16) st4(dst + 4 * c, ld4(src + 4 * c));      // (observations wider than 128 floats)
+    }
+  }
+  float lp = 0.f, lp2 = 0.f;
+  if (sub < p.a) {
+    const int j = sub;
+    const float v0 = u0 + e_bh0;
+    float act;
+    if (p.sac) {
+      const float v1 = u1 + e_bh1;
+      const float tt = tanhf(v1);
+      const float log_std = -5.0f + 3.5f * (tt + 1.0f);
+      const float sd = expf(log_std);
+      const float x = v0 + e * sd;
+      const float yt = tanhf(x);
+      act = yt * e_sc + e_bi;
+      const float dx = x - v0;
+      float l = -(dx * dx) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;
+      l -= logf(e_sc * (1.0f - yt * yt) + 1e-6f);
+      lp = l;
+      if (p.dual) {
+        const float x2 = v0 + e2 * sd, y2 = tanhf(x2), d2 = x2 - v0;
+        lp2 = -(d2 * d2) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f - logf(e_sc * (1.0f - y2 * y2) + 1e-6f);
+      }
+      if (p.mode == 1) act = tanhf(v0) * e_sc + e_bi;
+      if (p.train && valid) {
+        float* tg = p.tg + (long)b * 4 * p.a4;
+        tg[j] = tt; tg[p.a4 + j] = sd; tg[2 * p.a4 + j] = yt;
+      }
+    } else {
+      const float th = tanhf(v0);
+      act = th * e_sc + e_bi;
+      if (p.mode == 1) {
+        const float nz = fminf(fmaxf(e * p.td3_std, -p.td3_c), p.td3_c);
+        act = fminf(fmaxf(act + nz, e_lo), e_hi);
+      } else if (p.mode == 2) {
+        act = act + e * (e_sc * p.noise_std);
+      }
+      if (p.train && valid) p.tg[(long)b * 4 * p.a4 + j] = th;
+    }
+    if (valid) p.dst[(long)b * p.ldd + p.dst_off + j] = act;
+  }
+  if (p.sac && p.logp) {
+    lp = row16_sum(lp);
+    if (sub == 0 && valid) p.logp[b] = lp;
+  }
+  if (p.dual) {
+    lp2 = row16_sum(lp2);
+    if (sub == 0 && valid) p.logp2[b] = lp2;
+  }
+  if (ticker) *p.tick = tick_v + 1;
 }
 
 struct CriticTail {
