@@ -106,6 +106,7 @@ struct sactd3_engine {
   float* eps[SACTD3_NUM_SITES] = {};
   float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
+  float* a_z2n = nullptr;        // layer-2 output of the s' pass when the pi(s) pass shares its launch
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
   float* s_h1 = nullptr;         // large-batch path: layer-1 activations of nets whose caller keeps no copy ([4][B][256])
@@ -236,7 +237,7 @@ static void launch_nt_f1(hipStream_t s, int ks, int nt, dim3 grid, const NtArgs&
 }
 // pro == 0: the generic-K form (unfused first layer).  Otherwise K == 256 and the block shape (16 / 32 / 64 rows x 16
 // columns) is chosen so that the launch has about one block per CU.
-static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro, bool fuse1, const NtArgs& g, int nets) {
+static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro, bool fuse1, const NtArgs& g, int nets, int force_ks = 0) {
   const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
   // algorithmic work: the (fused) first layer + this layer; operands: input rows, the weight blocks, the output (+ stored activations)
   const double fl = 2.0 * nets * (double)g.M * g.N * (g.K + (fuse1 ? g.K1 : 0));
@@ -252,11 +253,12 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     const int tiles = tiles_m * tiles_n * nets;
     int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
     if (e->tune_ks) ks = e->tune_ks;
+    if (force_ks) ks = force_ks;
     const int rb = 64 / ks;
     // two column tiles per block when the launch would otherwise put two rounds of blocks on every CU: the fused first
     // layer is then recomputed (or the A rows fetched and normalised) by half as many blocks
     int nt = (ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
-    if (e->tune_nt == 1) nt = 1;
+    if (e->tune_nt == 1 || force_ks) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
     const int nzb = fuse1 ? (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0) : 0;
@@ -383,10 +385,12 @@ static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] 
 // The two hidden layers of MLP trunks: z2 = relu(LN(x W1^T + b1)) W2^T + b2 for up to two groups of nets
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
-struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; };
+struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; int ring_off = 0; };
 struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false;
                     const AlphaArgs* alpha = nullptr;      // alpha: a pending temperature step to carry as one extra block
-                    int nnoise = 0; NoiseJob noise[2] = {}; bool* noise_taken = nullptr; };   // the following tail's draws (see NoiseJob)
+                    int nnoise = 0; NoiseJob noise[2] = {}; bool* noise_taken = nullptr;      // the following tail's draws (see NoiseJob)
+                    int force_ks = 0;                      // keep the single-net launch's K split (bit-equal results across launch shapes)
+                    int* tick0b = nullptr; float* adam_out_b = nullptr; double* adam_pw_b = nullptr; float lr_b = 0.f; };   // a second step counter
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
   const int pro = e->cfg.layer_norm ? 1 : 2;
@@ -443,10 +447,12 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
       if (tk.noise_taken) *tk.noise_taken = true;
     }
     if (tk.fuse_gather) {   // x = the s' field of the sampled records; extra blocks fill the batch slot (see NtArgs)
-      h.ring_rows = 1; h.ring_off = e->ldc; h.ga = gather_args(e, e->ring, -1);
+      h.ring_rows = 1; h.ga = gather_args(e, e->ring, -1);
+      for (int i = 0; i < ngrp; ++i) h.g[i].ring_off = grp[i].ring_off;
       h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
     }
-    return launch_nt(e, s, "layers1+2", pro, true, h, nets);
+    h.tick0b = tk.tick0b; h.adam_out_b = tk.adam_out_b; h.adam_pw_b = tk.adam_pw_b; h.lr_b = tk.lr_b;
+    return launch_nt(e, s, "layers1+2", pro, true, h, nets, tk.force_ks);
   }
   NtArgs g{};
   g.npg = npg; g.oW = L.W1; g.ldw = L.ld1; g.oBias = L.b1; g.p_ns = p_ns; g.ld_in = ldx; g.in_ns = 0;
@@ -520,26 +526,51 @@ static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
 // agents/agent.py:183-242
 // fused_sample: this update opens a fused iteration and owns the replay sampling (orchestrator.py:338); with a narrow
 // observation the gather rides in the first trunk kernel, otherwise enqueue_step has launched k_gather just before.
-static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ) {
+// with_policy: also run the first actor update's policy pass pi(s) in the opening launches (fused iterations with actor updates);
+// *policy_done tells the caller whether that happened.
+static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ,
+                                bool with_policy = false, bool* policy_done = nullptr) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
-  e->node_role = fused_sample ? "critic/next-action+sample" : "critic/next-action";
+  e->node_role = fused_sample ? (with_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
   {
-    const TrunkGrp g{e->Xn, Pact, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
     const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
+    const bool merge_policy = with_policy && in_kernel_gather;      // the FIRST actor update's pi(s) pass rides along (see enqueue_step)
+    TrunkGrp g[2] = {{e->Xn, Pact, e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
+                     {e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
     tk.fuse_gather = in_kernel_gather;
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     bool eps_ready = false;
-    if (!td3 || mode == 1) { tk.nnoise = 1; tk.noise[0] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise_taken = &eps_ready; }
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
-    ActorTail t = tail_args(e, e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
+    if (!td3 || mode == 1) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise_taken = &eps_ready; }
+    if (merge_policy) {
+      // the policy sample of the first actor update: same actor parameters (the critic update does not touch them), the stream
+      // counter one ahead (the critic update's last kernel bumps it before the actor update would have read it)
+      if (!td3) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, 1, B); tk.noise_taken = &eps_ready; }
+      tk.force_ks = 4;
+      tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
+    }
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, merge_policy ? 2 : 1, 1, g, tk));
+    ActorTail t = tail_args(e, merge_policy ? e->a_z2n : e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
     t.eps_ready = eps_ready;
     if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
-    RCCHK(launch_tail(e, s, t));
+    if (merge_policy && tail_rows_per_block(t) == 4) {
+      ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
+      const int nb = (B + 3) / 4;
+      LAUNCH("k_actor_tail_s2<4>", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
+             k_actor_tail_s2<4>, dim3(2 * nb), dim3(64), t, t1, nb);
+      if (policy_done) *policy_done = true;
+    } else if (merge_policy) {                  // (wide heads: the two tails as two launches of the general kernel)
+      RCCHK(launch_tail(e, s, t));
+      ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1; t1.eps_ready = eps_ready;
+      RCCHK(launch_tail(e, s, t1));
+      if (policy_done) *policy_done = true;
+    } else RCCHK(launch_tail(e, s, t));
   }
   {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232).
      // (Measured: running the online pair on a fork/join side branch of the graph instead costs +30 us per replay on
@@ -744,11 +775,12 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
   if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
-  RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr));
+  bool policy_done = false;
+  RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr, do_actor, &policy_done));
   if (do_actor) {
     const int n = e->cfg.actor_update_delay;
     const bool can_merge = !td3 && e->cfg.autotune;
-    for (int j = 0; j < n; ++j) RCCHK(enqueue_update_actor(e, s, j, can_merge && j > 0, can_merge && j + 1 < n));
+    for (int j = 0; j < n; ++j) RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && j + 1 < n));
   }
   if (do_polyak && td3) RCCHK(enqueue_polyak(e, s, true, true));
   return 0;
@@ -878,7 +910,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
     RCCHK(dalloc(e, &e->eps[s], std::max<size_t>(B, e->maxn) * e->a));
   RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_xh1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_rs1, B));
   RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_xh2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_rs2, B));
-  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu));
+  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu)); RCCHK(dalloc(e, &e->a_z2n, BH));
   RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
   RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_xh1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_rs1, 2 * B));
   RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));

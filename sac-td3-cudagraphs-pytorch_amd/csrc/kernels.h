@@ -441,6 +441,7 @@ struct NtGrp {               // one group of nets sharing an input and a paramet
   const float* P;                           // parameter arena of the group's first net; net stride p_ns
   float* Y;                                 // output, net stride y_ns
   float* xh_out; float* h_out; float* rstd_out;   // optional stores of the prologue rows by the column-tile-0 blocks
+  int ring_off;                             // ring_rows: float offset of this group's input field inside a replay record
 };
 struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = one 16 x 16 output tile, K split over the 4 waves
   NtGrp g[2]; int npg;                      // blockIdx.z = grp * npg + net-in-group
@@ -456,7 +457,9 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // Fused replay sampling (first kernel of a fused iteration, FUSE1 only): the x rows are read straight from the replay
   // ring (row = this sample's index, field offset ring_off floats) and `gblocks` extra blocks at the end of the grid do
   // the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.
-  int ring_rows; int ring_off; int nt_blocks; int gblocks; GatherArgs ga;
+  int ring_rows; int nt_blocks; int gblocks; GatherArgs ga;
+  // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
+  int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
   // One more block (after the gather blocks, net 0 only) can carry the temperature step of the PREVIOUS actor update
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
@@ -506,8 +509,9 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   const int mt = wave / KS, ks = wave % KS;
-  if (blockIdx.x == 0 && t == 0 && net == 0) {
-    if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
+  if (blockIdx.x == 0 && net == 0) {
+    if (t == 0 && (p.tick0 || p.tick1)) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
+    if (FUSE1 && t == 64 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       const unsigned long long seed = p.ga.ctl->seed;
       int id = (int)philox_index(seed, (unsigned)sctr, (unsigned)mrow, (unsigned)max(rb_len, 1));
       if (inject) id = p.ga.idx[mrow];
-      xrow = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + p.ring_off;
+      xrow = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + G.ring_off;
     }
 #pragma unroll
     for (int c1 = 0; c1 < C1; ++c1) {
@@ -1475,7 +1479,9 @@ struct ActorTail {
 // must not be read from memory a second time
 __device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr,
                                            int bc, int b, int j, bool valid) {
-  if (p.eps_ready || p.ctl->inject_eps[site_buf]) return eps[(long)bc * p.a + j];
+  const int inj = p.ctl->inject_eps[site_buf] | p.eps_ready;     // flag and buffered value requested together
+  const float buffered = eps[(long)bc * p.a + j];
+  if (inj) return buffered;
   const float e = philox_normal(p.ctl->seed, (unsigned)ctr, site_code, (unsigned)(bc * p.a + j));
   if (valid) eps[(long)b * p.a + j] = e;
   return e;
@@ -1678,13 +1684,13 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
 // differs, inside the 1e-5 budget of north_star); dual draws, training stores, the [s | pi(s)] row build and the counter
 // tick behave identically.
 template <int RPB>
-__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s(ActorTail p) {
+__device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block) {
   const int t = threadIdx.x, row = t >> 4, sub = t & 15;
-  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
+  const int b = block * RPB + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const int nh = p.L.nh;                         // <= 8, and a <= 8
   const float* Wh = p.P + p.L.Wh;
-  const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
+  const bool ticker = p.tick && block == 0 && t == 0;
   int tick_v = 0;
   if (ticker) tick_v = *p.tick;
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
@@ -1805,6 +1811,15 @@ __global__ __launch_bounds__(16 * RPB) void k_actor_tail_s(ActorTail p) {
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
   if (ticker) *p.tick = tick_v + 1;
+}
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s(ActorTail p) { actor_tail_s_body<RPB>(p, blockIdx.x); }
+// two tails in one launch (blocks [0, nb_a) run `a`, the rest `b`): the critic update's target-action tail on s' and the first
+// actor update's policy tail on s -- same actor parameters, nothing between them depends on the other
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s2(ActorTail a, ActorTail b, int nb_a) {
+  if ((int)blockIdx.x < nb_a) actor_tail_s_body<RPB>(a, blockIdx.x);
+  else actor_tail_s_body<RPB>(b, blockIdx.x - nb_a);
 }
 
 struct CriticTail {

@@ -613,7 +613,8 @@ def test_calls_run_on_the_engines_device_whatever_the_current_device_is():
 
 def test_time_nodes_lists_the_iteration_graphs():
     """sactd3_time_nodes walks the same enqueue sequence the graphs are captured from: node counts agree with the
-    instantiated graphs (7 / 30 at Hopper shapes) and every node has a kernel-instance name, a grid and a time."""
+    instantiated graphs (7 / 28 at Hopper shapes: the first actor update's policy pass shares the opening two launches of the
+    iteration) and every node has a kernel-instance name, a grid and a time."""
     ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256)
     eng.rb_fill_synthetic(2000)
     for i in range(3):
@@ -621,7 +622,7 @@ def test_time_nodes_lists_the_iteration_graphs():
     eng.sync()
     n0, n1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
     g0, g1 = eng.time_nodes(False, 5), eng.time_nodes(True, 5)
-    assert (len(g0), len(g1)) == (n0, n1) == (7, 30)
+    assert (len(g0), len(g1)) == (n0, n1) == (7, 28)
     for n in g0 + g1:
         assert n["name"].startswith("k_") and ":" in n["name"] and n["threads"] > 0 and 0.0 < n["us"] < 1e4
     assert sum(n["flops"] for n in g0) > 0.3e9      # (critic update of SURVEY 8d: A + 8C per sample at B = 256)
