@@ -261,7 +261,7 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     if (e->tune_nt == 1 || force_ks) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
-    const int nzb = fuse1 ? (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0) : 0;
+    const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0) + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
     if (e->node_log) {
@@ -466,6 +466,11 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   } else RCCHK(launch_nt(e, s, "layer1", 0, false, g, nets));
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
+  if (tk.nnoise > 0) {   // (as in the fused form) the following tail's draws as extra blocks of the layer-2 launch
+    h.nz_n = tk.nnoise; h.nz_ctl = e->ctl;
+    for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
+    if (tk.noise_taken) *tk.noise_taken = true;
+  }
   return launch_nt(e, s, "layer2", pro, false, h, nets);
 }
 

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
-  if (FUSE1 && (p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
+  if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
     const int x = (int)blockIdx.x - p.nt_blocks;
     if (x < p.gblocks) gather_body(p.ga, x);
     else if (blockIdx.z != 0) { }
@@ -1473,23 +1473,6 @@ struct ActorTail {
   int eps_ready;                         // the eps buffers were filled by the preceding trunk launch's noise blocks: load, draw nothing
 };
 
-// the N(0,1) draw of output element j of row b: injected (parity tests) or the engine's Philox stream
-// (only for output elements beyond a thread's first, i.e. ac_dim > 16: the first one is handled branch-free in the kernel)
-// `ctr` is the stream counter the kernel read at its start: block 0 may bump the counter word at its end (p.tick), so it
-// must not be read from memory a second time
-__device__ __forceinline__ float tail_draw(const ActorTail& p, int site_buf, unsigned site_code, float* eps, int ctr,
-                                           int bc, int b, int j, bool valid) {
-  const int inj = p.ctl->inject_eps[site_buf] | p.eps_ready;     // flag and buffered value requested together
-  const float buffered = eps[(long)bc * p.a + j];
-  if (inj) return buffered;
-  const float e = philox_normal(p.ctl->seed, (unsigned)ctr, site_code, (unsigned)(bc * p.a + j));
-  if (valid) eps[(long)b * p.a + j] = e;
-  return e;
-}
-__device__ __forceinline__ float tail_noise(const ActorTail& p, bool need_eps, int ctr, int bc, int b, int j, bool valid) {
-  return need_eps ? tail_draw(p, p.site_buf, p.site_code, p.eps, ctr + p.ctr_add, bc, b, j, valid) : 0.f;
-}
-
 // Memory discipline of this kernel (and of every kernel here): ALL global loads of the common case go out first, behind
 // uniform branches only and with clamped addresses + selects instead of per-lane conditions; they are made to land
 // (PIN) before the first global store.  A load that follows a store, or one that is first used inside a divergent
@@ -1535,21 +1518,42 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   float e_in1 = 0.f, e_in2 = 0.f;
   if (need_eps) e_in1 = p.eps[ej];               // fetched whether or not it is an injected draw: branching on the
   if (p.dual) e_in2 = p.eps2[ej];                // (loaded) injection flag here would hold back every later request
-  // observation slice to copy (builds [s | pi(s)] rows): 16-byte chunks sub and sub + 16 of the row and the < 4 trailing
-  // floats (the chunk that straddles the action columns is NOT moved as a whole: another thread writes the action there)
+  // a second output element per thread when ac_dim > 16 (Humanoid: 17): its operands are requested here with everything else
+  // (fetched one by one behind the first element, as this kernel first did, they were 3-4 dependent round trips)
+  const bool two = p.a > 16;                     // (uniform)
+  const int j1 = min(sub + 16, p.a - 1);
+  const long ej1 = (long)bc * p.a + j1;
+  float f_bh0 = 0.f, f_bh1 = 0.f, f_sc = 0.f, f_bi = 0.f, f_lo = 0.f, f_hi = 0.f, f_in1 = 0.f, f_in2 = 0.f;
+  if (two) {
+    f_bh0 = p.P[p.L.bh + j1]; f_bh1 = p.sac ? p.P[p.L.bh + p.a + j1] : 0.f;
+    f_sc = p.scale[j1]; f_bi = p.bias[j1];
+    if (smooth) { f_lo = p.min_ac[j1]; f_hi = p.max_ac[j1]; }
+    if (need_eps) f_in1 = p.eps[ej1];
+    if (p.dual) f_in2 = p.eps2[ej1];
+  }
+  // observation slice to copy (builds [s | pi(s)] rows): 16-byte chunks sub, sub + 16, ... of the row (up to 8 per thread:
+  // 512 floats) and the < 4 trailing floats (the chunk that straddles the action columns is NOT moved as a whole: another
+  // thread writes the action there); wider observations finish in a loop behind the stores
   const int o4 = p.o >> 2, orem = p.o & 3;
-  float4 ob4[2] = {f4(0.f), f4(0.f)};
+  constexpr int OBC = 8;
+  float4 ob4[OBC];
   float obt = 0.f;
+  const int nob = p.obs_src ? min((o4 + 15) >> 4, OBC) : 0;     // (uniform) chunks per thread actually needed
+#pragma unroll
+  for (int i = 0; i < OBC; ++i) ob4[i] = f4(0.f);
   if (p.obs_src) {
     const float* srow = p.obs_src + (long)bc * p.lds;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ob4[i] = ld4(srow + 4 * min(sub + 16 * i, max(o4 - 1, 0)));
+    for (int i = 0; i < OBC; ++i)
+      if (i < nob) ob4[i] = ld4(srow + 4 * min(sub + 16 * i, max(o4 - 1, 0)));
     obt = srow[min(4 * o4 + sub, p.o - 1)];
   }
   // native draws (no memory involved)
   const bool gen = !p.eps_ready;                 // (uniform)
   const float e_nat1 = (gen && need_eps) ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej) : 0.f;
   const float e_nat2 = (gen && p.dual) ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej) : 0.f;
+  const float f_nat1 = (gen && two && need_eps) ? philox_normal(seed, (unsigned)(ctr + p.ctr_add), p.site_code, (unsigned)ej1) : 0.f;
+  const float f_nat2 = (gen && two && p.dual) ? philox_normal(seed, (unsigned)ctr, p.site_code2, (unsigned)ej1) : 0.f;
   STAMP(1);
   Row16 xh, y; float rstd;
   ln_fwd(z, g, be, p.ln, xh, y, rstd);
@@ -1566,11 +1570,15 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       if (tt * 16 + r >= nh) wf[tt][ci] = f4(0.f);
     }
   PIN(e_bh0); PIN(e_bh1); PIN(e_sc); PIN(e_bi); PIN(e_lo); PIN(e_hi); PIN(e_in1); PIN(e_in2); PIN(tick_v);
+  PIN(f_bh0); PIN(f_bh1); PIN(f_sc); PIN(f_bi); PIN(f_lo); PIN(f_hi); PIN(f_in1); PIN(f_in2);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
+  for (int i = 0; i < OBC; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
   PIN(obt);
   const float e_eps = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
   const float e_eps2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
+  const bool has2 = two && sub + 16 < p.a;
+  const float f_eps = (need_eps && has2) ? (inj1 ? f_in1 : f_nat1) : 0.f;
+  const float f_eps2 = (p.dual && has2) ? (inj2 ? f_in2 : f_nat2) : 0.f;
   if (valid) {
     if (p.train) {
       row_st(p.h2 + (long)b * HID, sub, h);
@@ -1581,14 +1589,18 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
       if (need_eps && !inj1) p.eps[ej] = e_nat1;
       if (p.dual && !inj2) p.eps2[ej] = e_nat2;
     }
+    if (has2) {
+      if (need_eps && !inj1) p.eps[ej1] = f_nat1;
+      if (p.dual && !inj2) p.eps2[ej1] = f_nat2;
+    }
     if (p.obs_src) {
       const float* __restrict__ src = p.obs_src + (long)b * p.lds;
       float* __restrict__ dst = p.dst + (long)b * p.ldd;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < OBC; ++i)
         if (sub + 16 * i < o4) st4(dst + 4 * (sub + 16 * i), ob4[i]);
       if (sub < orem) dst[4 * o4 + sub] = obt;
-      for (int c = sub + 32; c < o4; c += 64) {            // observations wider than 128: four chunks in flight per trip
+      for (int c = sub + 16 * OBC; c < o4; c += 64) {      // observations wider than 512 floats: four chunks in flight per trip
         float4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ld4(src + 4 * min(c + 16 * i, o4 - 1));
@@ -1659,11 +1671,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     if (valid) p.dst[(long)b * p.ldd + p.dst_off + j] = act;
   };
   if (sub < p.a) element(sub, e_bh0, e_bh1, e_sc, e_bi, e_lo, e_hi, e_eps, e_eps2);       // operands already in registers
-  for (int j = sub + 16; j < p.a; j += 16) {                                   // ac_dim > 16 only
-    const float e = tail_noise(p, need_eps, ctr, bc, b, j, valid);
-    const float e2 = p.dual ? tail_draw(p, p.site_buf2, p.site_code2, p.eps2, ctr, bc, b, j, valid) : 0.f;
-    element(j, p.P[p.L.bh + j], p.sac ? p.P[p.L.bh + p.a + j] : 0.f, p.scale[j], p.bias[j], smooth ? p.min_ac[j] : 0.f, smooth ? p.max_ac[j] : 0.f, e, e2);
-  }
+  if (has2) element(sub + 16, f_bh0, f_bh1, f_sc, f_bi, f_lo, f_hi, f_eps, f_eps2);       // ac_dim in 17 .. 32
   STAMP(4);
   if (p.sac && p.logp) {
     lp = row16_sum(lp);
