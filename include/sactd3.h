@@ -172,6 +172,11 @@ int sactd3_step_period(sactd3_engine* e);
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions);
 
 int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]);  /* [sync] */
+/* The engine's HIP stream (hipStream_t) and the DEVICE address of the metrics slots, for callers that want the values the
+ * way the reference hands them out -- 0-dim device tensors that are only materialised at evaluation time (agents/agent.py:
+ * 238-242,305-311; orchestrator.py:341,348,383): wrap `metrics + SACTD3_M_*` as a tensor and order the consumer's stream
+ * after `stream` (the Python mirror does both with torch).  The memory is owned by the engine and overwritten by later updates. */
+int sactd3_device_handles(sactd3_engine* e, void** stream, float** metrics);
 int sactd3_sync(sactd3_engine* e);                                          /* [sync] */
 
 /* ---- introspection for tests / profiling (not part of the reference surface) ---- */

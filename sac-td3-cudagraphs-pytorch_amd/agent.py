@@ -40,6 +40,16 @@ class LazyMetric:
         return f"LazyMetric({self._key})"
 
 
+class _DeviceScalar:
+    """__cuda_array_interface__ view of ONE float32 in the engine's device memory (a metrics slot)."""
+
+    def __init__(self, ptr: int):
+        self.__cuda_array_interface__ = {"shape": (), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+_METRIC_SLOT = {"loss/qf_loss": 0, "loss/actor_loss": 1, "loss/alpha_loss": 2, "vitals/alpha": 3}   # SACTD3_M_*
+
+
 class BatchHandle(dict):
     """What `rb.sample()` returns: the batch lives in the engine's HBM batch slot; indexing a key reads it back
     (host sync) as the reference's TensorDict keys would (observations, actions, rewards, next_observations,
@@ -95,9 +105,12 @@ class Agent:
 
     def __init__(self, net_shapes: Dict[str, tuple], min_ac: np.ndarray, max_ac: np.ndarray, device: Any,
                  hps: Any, rb: Optional[ReplayBuffer] = None, *, seed: Optional[int] = None,
-                 init_params: bool = True, use_graphs: Optional[bool] = None):
+                 init_params: bool = True, use_graphs: Optional[bool] = None, metrics: str = "tensor"):
         """`use_graphs`: None = the engine's own hipGraphs ON (whatever `hps.cudagraphs` says: that key steers the reference
-        loop's CudaGraphModule wrappers, orchestrator.py:313-315, which must stay off around these methods)."""
+        loop's CudaGraphModule wrappers, orchestrator.py:313-315, which must stay off around these methods).
+        `metrics`: "tensor" = update_* return 0-dim float32 CUDA tensors that alias the engine's metrics slots (zero copy; what
+        `tlog.update(...)` of orchestrator.py:302,341,348 expects -- a TensorDict takes them as is, and they are only read at
+        evaluation time, :383); "lazy" = host-side LazyMetric handles (no torch needed)."""
         ob_dim, ac_dim = int(net_shapes["ob_shape"][-1]), int(net_shapes["ac_shape"][-1])
         self.device, self.hps = device, hps
         self.min_ac, self.max_ac = np.asarray(min_ac, np.float32), np.asarray(max_ac, np.float32)
@@ -117,6 +130,18 @@ class Agent:
         assert getattr(hps, "segment_len", 1) <= cfg.batch_size  # agents/agent.py:47
         self.ob_dim, self.ac_dim, self.td3, self.ln = ob_dim, ac_dim, cfg.prefer_td3_over_sac, cfg.layer_norm
         self.engine = Engine(cfg, self.min_ac, self.max_ac)
+        self._metric_tensors: Optional[Dict[str, Any]] = None
+        self._ext_stream = None
+        if metrics != "lazy":   # 0-dim device tensors over the engine's metrics slots (what the reference's update_* return)
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    st, mp = self.engine.device_handles()
+                    dev = torch.device("cuda", cfg.device_id)
+                    self._metric_tensors = {k: torch.as_tensor(_DeviceScalar(mp + 4 * i), device=dev) for k, i in _METRIC_SLOT.items()}
+                    self._ext_stream = torch.cuda.ExternalStream(st, device=dev)
+            except Exception:   # noqa: BLE001 -- no torch / no cuda array interface: the lazy host-side handles remain
+                self._metric_tensors = None
         self.rb = rb
         if rb is not None:
             rb._bind(self.engine)
@@ -164,20 +189,29 @@ class Agent:
         """agents/agent.py:172-181 -> np.ndarray[n, ac_dim] float32 on the host."""
         return self.engine.predict(_np(in_td["observations"]), explore)
 
-    def update_qnets(self, batch) -> Dict[str, LazyMetric]:
+    def _results(self, keys) -> Dict[str, Any]:
+        if self._metric_tensors is None:
+            return {k: LazyMetric(self, k) for k in keys}
+        # the tensors alias memory the engine's stream writes: whoever reads them on torch's current stream does so after the
+        # work enqueued so far (an event wait between two streams, no host synchronisation)
+        import torch
+        torch.cuda.current_stream(self._ext_stream.device).wait_event(self._ext_stream.record_event())
+        return {k: self._metric_tensors[k] for k in keys}
+
+    def update_qnets(self, batch) -> Dict[str, Any]:
         self._stage(batch)
         self.engine.update_qnets()
-        return {"loss/qf_loss": LazyMetric(self, "loss/qf_loss")}
+        return self._results(["loss/qf_loss"])
 
-    def update_actor(self, batch) -> Dict[str, LazyMetric]:
+    def update_actor(self, batch) -> Dict[str, Any]:
         self._stage(batch)
         self.engine.update_actor()
-        out = {"loss/actor_loss": LazyMetric(self, "loss/actor_loss")}
+        keys = ["loss/actor_loss"]
         if not self.td3:  # agents/agent.py:288-318
             if self.engine.cfg.autotune:
-                out["loss/alpha_loss"] = LazyMetric(self, "loss/alpha_loss")
-            out["vitals/alpha"] = LazyMetric(self, "vitals/alpha")
-        return out
+                keys.append("loss/alpha_loss")
+            keys.append("vitals/alpha")
+        return self._results(keys)
 
     def update_targ_nets(self) -> None:
         self.engine.update_targ_nets(self.qnet_updates_so_far)

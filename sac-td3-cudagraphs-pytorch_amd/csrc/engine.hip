@@ -540,10 +540,10 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   const long BH = (long)B * HID;
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
-  e->node_role = fused_sample ? (with_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
   {
     const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
     const bool merge_policy = with_policy && in_kernel_gather;      // the FIRST actor update's pi(s) pass rides along (see enqueue_step)
+    e->node_role = fused_sample ? (merge_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
     TrunkGrp g[2] = {{e->Xn, Pact, e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
                      {e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
@@ -1364,6 +1364,13 @@ int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]) {
   USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, e->ctl->metrics, sizeof(float) * SACTD3_NUM_METRICS, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sactd3_device_handles(sactd3_engine* e, void** stream, float** metrics) {
+  if (!e) return SACTD3_EINVAL;
+  if (stream) *stream = (void*)e->stream;
+  if (metrics) *metrics = e->ctl->metrics;
   return 0;
 }
 

@@ -278,6 +278,12 @@ class Engine:
     def sync(self) -> None:
         self._ck(self.lib.sactd3_sync(self._h))
 
+    def device_handles(self):
+        """(hipStream_t of the engine, device address of the float32 metrics slots) as integers."""
+        st, mp = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.sactd3_device_handles(self._h, C.byref(st), C.byref(mp)))
+        return int(st.value or 0), int(mp.value or 0)
+
     # -- introspection
     def debug_read(self, name: str) -> np.ndarray:
         n = int(self._ck(self.lib.sactd3_debug_read(self._h, name.encode(), None, 0)))

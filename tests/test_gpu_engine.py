@@ -630,6 +630,36 @@ def test_time_nodes_lists_the_iteration_graphs():
     assert all(np.isfinite(v) for v in eng.read_metrics().values())
 
 
+def test_update_results_are_zero_dim_device_tensors():
+    """agents/agent.py:238-242,305-311 return 0-dim DEVICE tensors that orchestrator.py:341,348 put into `tlog` and :383 reads
+    at evaluation time.  The mirror returns 0-dim float32 CUDA tensors that alias the engine's metrics slots (no copy, no host
+    sync when returned); read later they hold the latest values; `metrics="lazy"` keeps the torch-free handles."""
+    from types import SimpleNamespace
+    o, a, bound = DIMS["hopper"]
+    mk = lambda **kw: P.Agent({"ob_shape": (o,), "ac_shape": (a,)}, np.full(a, -bound, np.float32), np.full(a, bound, np.float32), torch.device("cuda:0"),
+                              SimpleNamespace(**{**Hps.sac(batch_size=64).__dict__, "rb_capacity": 512, "seed": 0}), P.ReplayBuffer(512), **kw)
+    ag = mk()
+    ag.engine.rb_fill_synthetic(400)
+    tlog = {}
+    for i in range(3):
+        batch = ag.rb.sample(64)
+        tlog.update(ag.update_qnets(batch))
+        tlog.update(ag.update_actor(batch))
+        ag.qnet_updates_so_far += 1
+        ag.update_targ_nets()
+    assert set(tlog) == {"loss/qf_loss", "loss/actor_loss", "loss/alpha_loss", "vitals/alpha"}
+    for k, v in tlog.items():
+        assert isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 0 and v.dtype == torch.float32, k
+    got = {k: v.item() for k, v in tlog.items()}                     # what tlog.to_dict() materialises at eval time
+    assert got == ag.engine.read_metrics()
+    stacked = torch.stack(list(tlog.values()))                       # usable as ordinary tensors (e.g. by a TensorDict)
+    assert stacked.shape == (4,) and torch.isfinite(stacked).all()
+    lazy = mk(metrics="lazy")
+    lazy.engine.rb_fill_synthetic(400)
+    r = lazy.update_qnets(lazy.rb.sample(64))
+    assert isinstance(r["loss/qf_loss"], P.agent.LazyMetric) and np.isfinite(float(r["loss/qf_loss"]))
+
+
 # ------------------------------------------------------------------------------------------ config corners
 
 @pytest.mark.parametrize("algo,env,B,hp", [
