@@ -367,9 +367,12 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   }
   char inst[96];
   snprintf(inst, sizeof(inst), "k_tn<%d>.%s", kt, name);
-  if (!node_on(e, inst, fl, by, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256))) return 0;
-  if (kt == 2) hipLaunchKernelGGL(k_tn<2>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(k_tn<1>, dim3((unsigned)tiles, 1, (unsigned)nets), dim3(256), 0, s, g);
+  g.tiles = tiles;
+  if (g.pk_blocks) by += 12.0 * (g.pk.n0 + g.pk.n1);
+  const dim3 grid((unsigned)(tiles + g.pk_blocks), 1, (unsigned)nets);
+  if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
+  if (kt == 2) hipLaunchKernelGGL(k_tn<2>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(k_tn<1>, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -533,8 +536,10 @@ static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
 // observation the gather rides in the first trunk kernel, otherwise enqueue_step has launched k_gather just before.
 // with_policy: also run the first actor update's policy pass pi(s) in the opening launches (fused iterations with actor updates);
 // *policy_done tells the caller whether that happened.
+// actor_targ_rides: (TD3, fused iteration without actor updates) the actor target's Polyak update as extra blocks of the
+// weight-gradient launch; *actor_targ_done reports whether the launch could carry it.
 static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ,
-                                bool with_policy = false, bool* policy_done = nullptr) {
+                                bool with_policy = false, bool* policy_done = nullptr, bool actor_targ_rides = false, bool* actor_targ_done = nullptr) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
@@ -621,7 +626,13 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
     g.loss_part = e->part_s; g.loss_n = 2 * e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;   // unused tail entries stay 0
     g.loss_dst = &e->ctl->metrics[SACTD3_M_QF_LOSS]; g.tick = &e->ctl->noise_ctr;
-    RCCHK(launch_tn(e, s, fused_polyak_targ ? "dW+adam+polyak" : "dW+adam", g, 2));
+    const bool rides = actor_targ_rides && !(B >= BIG_BATCH && e->Gp);       // (the split-M route has no riding blocks)
+    if (rides) {
+      g.pk.t0 = e->Ta; g.pk.p0 = e->Pa; g.pk.n0 = e->La.size; g.pk.tau = c.polyak;
+      g.pk_blocks = (int)std::min<long>(64, (e->La.size / 4 + 255) / 256);
+      if (actor_targ_done) *actor_targ_done = true;
+    }
+    RCCHK(launch_tn(e, s, fused_polyak_targ ? (rides ? "dW+adam+polyak & actor-target polyak" : "dW+adam+polyak") : "dW+adam", g, 2));
   }
   return 0;
 }
@@ -629,7 +640,9 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
 // agents/agent.py:244-318.  j = index of this actor update inside the iteration (selects the noise buffers).
 // head_done: this update's policy sample was already produced by the previous update's dual tail (fused iteration);
 // merge_next: produce the NEXT update's policy sample together with this update's temperature draw.
-static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false) {
+// polyak_targ: (TD3, last actor update of a fused iteration) lerp the actor target towards the freshly stepped actor in the same
+// kernel that applies the step (agents/agent.py:331 after :286)
+static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false, float* polyak_targ = nullptr) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
@@ -707,17 +720,18 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, e->X, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
     if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
-    g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = nullptr; g.adam = e->ctl->adam_a;
+    g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = clip ? nullptr : polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_a;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
     g.loss_part = e->part_sa; g.loss_n = e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
     g.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS]; g.tick = (td3 && !clip) ? &e->ctl->noise_ctr : nullptr;
-    RCCHK(launch_tn(e, s, clip ? "dW" : "dW+adam", g, 1));
+    RCCHK(launch_tn(e, s, clip ? "dW" : (polyak_targ ? "dW+adam+polyak" : "dW+adam"), g, 1));
   }
   if (clip) {
     NormArgs n{e->Ga, (long)e->La.size, c.clip_norm, e->gscale};
     LAUNCH("k_gradnorm", 0.0, 4.0 * e->La.size, k_gradnorm, dim3(1), dim3(1024), n);
     AdamArgs a = adam_args(e, e->Pa, e->Ga, e->Ma, e->Va, e->La.size, e->ctl->adam_a);
     a.gscale = e->gscale;
+    a.targ = polyak_targ; a.tau = c.polyak;
     a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_adam(e, s, a));
   }
@@ -780,14 +794,25 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
   if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
-  bool policy_done = false;
-  RCCHK(enqueue_update_qnets(e, s, true, (do_polyak && !td3) ? e->Tc : nullptr, do_actor, &policy_done));
+  // Target updates (agents/agent.py:320-331) are folded into the kernels that apply the optimiser steps: the critic targets are
+  // lerped towards the freshly stepped critics inside the critics' Adam epilogue (same element, same order as :328 after :236;
+  // nothing between there and the end of the iteration reads the targets).  TD3 also moves the actor target every iteration:
+  // in the last actor update's Adam epilogue when the iteration has actor updates, otherwise -- the actor did not change -- as a
+  // few extra blocks of the critics' weight-gradient launch.
+  bool policy_done = false, actor_targ_done = false;
+  const bool actor_targ = do_polyak && td3;
+  RCCHK(enqueue_update_qnets(e, s, true, do_polyak ? e->Tc : nullptr, do_actor, &policy_done, actor_targ && !do_actor, &actor_targ_done));
   if (do_actor) {
     const int n = e->cfg.actor_update_delay;
     const bool can_merge = !td3 && e->cfg.autotune;
-    for (int j = 0; j < n; ++j) RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && j + 1 < n));
+    for (int j = 0; j < n; ++j) {
+      const bool last = j + 1 == n;
+      float* pt = nullptr;
+      if (actor_targ && last) { pt = e->Ta; actor_targ_done = true; }
+      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt));
+    }
   }
-  if (do_polyak && td3) RCCHK(enqueue_polyak(e, s, true, true));
+  if (actor_targ && !actor_targ_done) RCCHK(enqueue_polyak(e, s, false, true));
   return 0;
 }
 

@@ -928,6 +928,18 @@ __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
   STAMP(4);
 }
 
+// agents/agent.py:328-331: t <- t + tau (p - t) over up to two arenas; `block` of `nblocks` blocks of 256 threads
+struct PolyakArgs { float* t0; const float* p0; long n0; float* t1; const float* p1; long n1; float tau; };
+__device__ __forceinline__ void polyak_body(const PolyakArgs& a, unsigned block, unsigned nblocks) {
+  const long n = a.n0 + a.n1;
+  for (long i = ((long)block * 256 + threadIdx.x) * 4; i < n; i += (long)nblocks * 1024) {
+    float* t = i < a.n0 ? a.t0 + i : a.t1 + (i - a.n0);
+    const float* p = i < a.n0 ? a.p0 + i : a.p1 + (i - a.n0);
+    const float4 tt = ld4(t);
+    st4(t, tt + (ld4(p) - tt) * a.tau);
+  }
+}
+
 struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T * X[M,K] (columns K..ldw-1 are 0)
   const float* dY; int ldy; long dy_ns; int N;
   const float* X; int ldx; long x_ns; int K;
@@ -948,6 +960,9 @@ struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16
   const float* part; int pstride; const float* part_s;   // pstride = partial blocks allocated per net
   // extras done once by block 0 / net 0: loss finalisation and a counter tick
   const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
+  // `pk_blocks` more blocks (net 0, after the `tiles` GEMM blocks) run a Polyak update of an arena this launch does not
+  // otherwise touch (TD3: the actor target in the iterations that have no actor update, agents/agent.py:329-331)
+  int tiles; int pk_blocks; PolyakArgs pk;
 };
 
 struct AdamState { float w, m, v, t; };
@@ -977,6 +992,10 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ float cred[4 * 16 * 17];                    // [entry: 3 finalised vectors + the bias][16 partial groups][16 columns]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
+  if (p.pk_blocks && (int)blockIdx.x >= p.tiles) {          // (block-uniform) the riding Polyak update
+    if (net == 0) polyak_body(p.pk, blockIdx.x - p.tiles, p.pk_blocks);
+    return;
+  }
   int pi = 0;
   if (p.nprob > 1 && (int)blockIdx.x >= p.pr[1].tile0) pi = 1;
   if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
@@ -2199,16 +2218,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   }
 }
 
-struct PolyakArgs { float* t0; const float* p0; long n0; float* t1; const float* p1; long n1; float tau; };
-__global__ __launch_bounds__(256) void k_polyak(PolyakArgs a) {
-  const long n = a.n0 + a.n1;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
-    float* t = i < a.n0 ? a.t0 + i : a.t1 + (i - a.n0);
-    const float* p = i < a.n0 ? a.p0 + i : a.p1 + (i - a.n0);
-    const float4 tt = ld4(t);
-    st4(t, tt + (ld4(p) - tt) * a.tau);
-  }
-}
+__global__ __launch_bounds__(256) void k_polyak(PolyakArgs a) { polyak_body(a, blockIdx.x, gridDim.x); }
 
 struct NormArgs { const float* g; long n; float clip; float* gscale; };
 __global__ __launch_bounds__(1024) void k_gradnorm(NormArgs a) {   // single block; clip_grad_norm_ (agents/agent.py:284-285)
