@@ -120,7 +120,7 @@ struct sactd3_engine {
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
-  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0;
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
   // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
@@ -307,7 +307,7 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
     t.w_off = q.w_off; t.ldw = q.ldw; t.b_off = q.b_off;
     t.tiles_n = (q.N + TN64_N - 1) / TN64_N; t.tiles_k = (q.ldw + TN64_K - 1) / TN64_K; t.tile0 = tiles;
     tiles += t.tiles_n * t.tiles_k;
-    for (int f = 0; f < q.nfin; ++f) { r.vec[r.nvec].off = q.fin_off[f]; r.vec[r.nvec].slot = q.fin_slot[f]; ++r.nvec; r.vec_nblk = q.fin_nblk[f]; }
+    for (int f = 0; f < q.nfin; ++f) { r.vec[r.nvec].off = q.fin_off[f]; r.vec[r.nvec].slot = q.fin_slot[f]; r.vec[r.nvec].nblk = q.fin_nblk[f]; ++r.nvec; }
     if (q.fin_s_off >= 0) { r.s_off = q.fin_s_off; r.s_nblk = q.fin_s_nblk; }
     fl += 2.0 * nets * (double)g.M * q.N * q.K;
     by += 4.0 * nets * (double)g.M * (q.N + q.K);
@@ -597,7 +597,8 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.pstride = e->nblk4;
-    LAUNCH("k_critic_tail<16>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), t);
+    if (e->tune_rows4 & 1) LAUNCH("k_critic_tail<4>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<4>, dim3(e->nblk4, 2), dim3(64), t);
+    else LAUNCH("k_critic_tail<16>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), t);
   }
   {  // dh1 = dz2 W2
     NnArgs g{};
@@ -610,17 +611,19 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = ln;
     l.dz = e->c_dz1; l.part = e->part; l.pstride = e->nblk4;
-    LAUNCH("k_ln_bwd<16>", 0.0, 4.0 * 2 * (4.0 * BH + B + HID), k_ln_bwd<16>, dim3(e->nblk, 2), dim3(256), l);
+    if (e->tune_rows4 & 2) LAUNCH("k_ln_bwd<4>", 0.0, 4.0 * 2 * (4.0 * BH + B + HID), k_ln_bwd<4>, dim3(e->nblk4, 2), dim3(64), l);
+    else LAUNCH("k_ln_bwd<16>", 0.0, 4.0 * 2 * (4.0 * BH + B + HID), k_ln_bwd<16>, dim3(e->nblk, 2), dim3(256), l);
   }
   {  // every critic gradient + the Adam step (+ Polyak) in one launch:
      //   dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead ; dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
     TnArgs g{};
     g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
     g.pr[0] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
-    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, e->nblk); tn_fin(g.pr[0], 1, e->Lc.be2, e->nblk); }
-    tn_fin(g.pr[0], 2, e->Lc.Wh, e->nblk); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = e->nblk;
+    const int nb_tail = (e->tune_rows4 & 1) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
+    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[0], 1, e->Lc.be2, nb_tail); }
+    tn_fin(g.pr[0], 2, e->Lc.Wh, nb_tail); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = nb_tail;
     g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, e->X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
-    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1, e->nblk); tn_fin(g.pr[1], 4, e->Lc.be1, e->nblk); }
+    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[1], 4, e->Lc.be1, nb_ln); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
@@ -903,6 +906,8 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
+  if (const char* f = getenv("SACTD3_ROWS4")) e->tune_rows4 = atoi(f);
+  else e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;   // 4-row (single-wave) k_critic_tail / k_ln_bwd below B = 1024: -1.0 us per Hopper iteration, +-0 at Humanoid
   e->tune_tn64_min = e->num_cus / 2;
   if (const char* f = getenv("SACTD3_TN64_MIN")) e->tune_tn64_min = atoi(f);
   if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) e->tune_tn_kt = v; }

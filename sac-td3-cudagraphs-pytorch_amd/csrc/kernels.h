@@ -1371,13 +1371,13 @@ __global__ __launch_bounds__(256) void k_tn64(Tn64Args p) {
 // Sources by offset range: `vec` ranges come from part[net][blk][slot][256] summed over the row blocks (16 threads per
 // float4, DPP-reduced), one scalar from part_s[net][blk][0], everything else from the S <= 8 slabs.  Sums run in a fixed
 // order, so replays are bit-reproducible.
-struct AdamRedVec { int off; int slot; };
+struct AdamRedVec { int off; int slot; int nblk; };
 struct AdamRedArgs {
   const float* Gp; int S; int nets; long g_ns;           // slabs [S][nets][g_ns]
   float* G;                                              // gradient arena (always written)
   int apply; float* P; float* Mo; float* Vo; float* T; float tau;
   const float* adam; float b1, b2, eps;
-  AdamRedVec vec[5]; int nvec; int vec_nblk;             // 256-wide vectors finalised from row-block partials
+  AdamRedVec vec[5]; int nvec;                           // 256-wide vectors finalised from row-block partials (nblk blocks each)
   const float* part; int pstride;
   int s_off; int s_nblk; const float* part_s;            // one scalar element (critic head bias), s_off < 0: none
   const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
@@ -1428,19 +1428,18 @@ __global__ __launch_bounds__(256) void k_adam_red(AdamRedArgs a) {
   } else if (bx < main_blocks + 4 * a.nvec) {
     // one quarter of a 256-wide vector gradient: float4 column (t >> 4) + 16 quarter, 16 threads share its row-block partials
     const int e = (bx - main_blocks) >> 2, quarter = (bx - main_blocks) & 3;
-    int voff = a.vec[0].off, vslot = a.vec[0].slot;
-    if (e == 1) { voff = a.vec[1].off; vslot = a.vec[1].slot; }
-    if (e == 2) { voff = a.vec[2].off; vslot = a.vec[2].slot; }
-    if (e == 3) { voff = a.vec[3].off; vslot = a.vec[3].slot; }
-    if (e == 4) { voff = a.vec[4].off; vslot = a.vec[4].slot; }
+    int voff = a.vec[0].off, vslot = a.vec[0].slot, nb = a.vec[0].nblk;
+    if (e == 1) { voff = a.vec[1].off; vslot = a.vec[1].slot; nb = a.vec[1].nblk; }
+    if (e == 2) { voff = a.vec[2].off; vslot = a.vec[2].slot; nb = a.vec[2].nblk; }
+    if (e == 3) { voff = a.vec[3].off; vslot = a.vec[3].slot; nb = a.vec[3].nblk; }
+    if (e == 4) { voff = a.vec[4].off; vslot = a.vec[4].slot; nb = a.vec[4].nblk; }
     const int c4 = (t >> 4) + 16 * quarter, sub = t & 15;
     const long off = net * a.g_ns + voff + 4 * c4;
     float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
     if (a.apply && sub == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
     const float* pp = a.part + ((long)net * a.pstride * NSLOT + vslot) * HID + 4 * c4;
     float4 g = f4(0.f);
-    for (int blk = sub; blk < a.vec_nblk; blk += 64) {     // 4 independent requests per trip (one trip up to B = 1024)
-      const int nb = a.vec_nblk;
+    for (int blk = sub; blk < nb; blk += 64) {             // 4 independent requests per trip
       const float4 v0 = ld4(pp + (long)blk * NSLOT * HID), v1 = ld4(pp + (long)min(blk + 16, nb - 1) * NSLOT * HID);
       const float4 v2 = ld4(pp + (long)min(blk + 32, nb - 1) * NSLOT * HID), v3 = ld4(pp + (long)min(blk + 48, nb - 1) * NSLOT * HID);
       g = g + v0;
