@@ -120,7 +120,7 @@ struct sactd3_engine {
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
-  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0;
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0, tune_nn16 = 0;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
   // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
@@ -279,6 +279,18 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
   return 0;
 }
 static int launch_nn(sactd3_engine* e, hipStream_t s, const char* name, const NnArgs& g, int nets) {
+  if (g.M >= BIG_BATCH && g.Kout == HID && g.k_off == 0 && !e->tune_nn16) {   // large batch: LDS-tiled form, ~1 block per CU
+    const double fl = 2.0 * nets * (double)g.M * HID * HID, by = 4.0 * nets * (2.0 * g.M * HID + (double)HID * HID);
+    if (nets >= 2) {
+      const dim3 grid((unsigned)(((g.M + 31) / 32) * (HID / 64) * nets));
+      LAUNCH("k_nn64<2,2,2>.dh1", fl, by, (k_nn64<2, 2, 2>), grid, dim3(256), g);
+    } else {
+      const dim3 grid((unsigned)(((g.M + 31) / 32) * (HID / 32) * nets));
+      LAUNCH("k_nn64<2,2,1>.dh1", fl, by, (k_nn64<2, 2, 1>), grid, dim3(256), g);
+    }
+    (void)name;
+    return 0;
+  }
   const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 15) / 16)), 1, (unsigned)nets);
   LAUNCH(name, 2.0 * nets * (double)g.M * HID * g.Kout, 4.0 * nets * ((double)g.M * HID + (double)HID * g.Kout + (double)g.M * g.Kout),
          k_nn, grid, dim3(256), g);
@@ -906,6 +918,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
+  if (const char* f = getenv("SACTD3_NN16")) e->tune_nn16 = atoi(f);
   if (const char* f = getenv("SACTD3_ROWS4")) e->tune_rows4 = atoi(f);
   else e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;   // 4-row (single-wave) k_critic_tail / k_ln_bwd below B = 1024: -1.0 us per Hopper iteration, +-0 at Humanoid
   e->tune_tn64_min = e->num_cus / 2;

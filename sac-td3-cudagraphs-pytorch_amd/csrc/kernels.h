@@ -928,6 +928,94 @@ __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
   STAMP(4);
 }
 
+// Large-batch form of k_nn (M >= 1024, Kout = 256: the dh1 = dz2 W2 products): LDS-tiled like k_nt64 -- (16 WM) x (16 TT WN)
+// outputs per block, the 256-long reduction streamed in 64-wide double-buffered chunks, every operand byte fetched once per
+// block with full-line loads.  W is used as stored ([n][c], rows = the reduction index): its chunk is parked in that layout and
+// the B fragments are read as columns (4 ds_read_b32, conflict-free: row stride = 4 mod 8), so no transposed copy of the
+// weights exists anywhere.  k_nn's 16 x 16 tiles fetch 18 MB per launch for 4 MB of operands at B = 1024 (rocprofv3 FETCH_SIZE).
+template <int WM, int WN, int TT>
+__global__ __launch_bounds__(64 * WM * WN) void k_nn64(NnArgs p) {        // dX[M,256] = dY[M,256] W[256,256]
+  constexpr int TM = 16 * WM, TN = 16 * TT * WN, NTH = 64 * WM * WN, LSB = TN + 4;
+  constexpr int RA = 16 * TM / NTH, RB = (KC64 * TN / 4) / NTH;          // float4 per thread per chunk
+  static_assert(RA >= 1 && RB >= 1 && 16 * TM % NTH == 0 && (KC64 * TN / 4) % NTH == 0, "staging map");
+  __shared__ __attribute__((aligned(16))) float As[2][TM * LS64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC64 * LSB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave % WM, wn = wave / WM;
+  const int r = lane & 15, kq = lane >> 4;
+  const int tiles_n = HID / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
+  int L = blockIdx.x;
+  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }     // XCD-contiguous tile runs (see k_nt64)
+  const int net = L / tiles, idx = L - net * tiles;
+  const int bm = idx / tiles_n, bn = idx - bm * tiles_n;
+  const int m0 = bm * TM, n0 = bn * TN;
+  const float* A = p.dY + net * p.dy_ns;
+  const float* W = p.Wt + net * p.p_ns + p.k_off + n0;
+  // staging maps: A chunk = TM rows x 16 float4 -> (row = t >> 4 [+ NTH/16 u], c4 = t & 15); B chunk = 64 rows x TN/4 float4
+  const int sr0 = t >> 4, sc = (t & 15) * 4;
+  constexpr int BC4 = TN / 4;
+  const float* ap[RA];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) ap[u] = A + (long)min(m0 + sr0 + (NTH / 16) * u, p.M - 1) * HID + sc;
+  float4 ra[RA], rb[RB];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < RA; ++u) ra[u] = ld4(ap[u] + c * KC64);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) { const int i = t + NTH * u, row = i / BC4, c4 = i % BC4; rb[u] = ld4(W + (long)(c * KC64 + row) * p.ldw + 4 * c4); }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + (NTH / 16) * u) * LS64 + sc, ra[u]);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) { const int i = t + NTH * u, row = i / BC4, c4 = i % BC4; st4(Bs[buf] + row * LSB + 4 * c4, rb[u]); }
+  };
+  f32x4 acc[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  park(0);
+  __syncthreads();
+  constexpr int nc = HID / KC64;
+  for (int c = 0; c < nc; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nc) fetch(c + 1);                 // next chunk's loads fly under this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    const float* ab = As[buf] + (16 * wm + r) * LS64 + 4 * kq;
+    const float* bb = Bs[buf] + (4 * kq) * LSB + 16 * TT * wn + r;
+#pragma unroll
+    for (int s2 = 0; s2 < KC64 / 16; ++s2) {
+      const float4 a = ld4(ab + 16 * s2);
+      float4 b[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const float* b0 = bb + 16 * s2 * LSB + 16 * tt;
+        b[tt] = make_float4(b0[0], b0[LSB], b0[2 * LSB], b0[3 * LSB]);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[tt].x, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[tt].y, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[tt].z, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[tt].w, acc[tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < nc) park(buf ^ 1);
+    __syncthreads();
+  }
+  float* x = p.dX + net * p.dx_ns;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int col = n0 + 16 * TT * wn + 16 * tt + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 16 * wm + 4 * kq + i;
+      if (row < p.M) x[(long)row * p.ldx + col] = acc[tt][i];
+    }
+  }
+}
+
 // agents/agent.py:328-331: t <- t + tau (p - t) over up to two arenas; `block` of `nblocks` blocks of 256 threads
 struct PolyakArgs { float* t0; const float* p0; long n0; float* t1; const float* p1; long n1; float tau; };
 __device__ __forceinline__ void polyak_body(const PolyakArgs& a, unsigned block, unsigned nblocks) {
