@@ -640,17 +640,21 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     }
   }
   STAMP(2);
-  if (PRO != 0 && tn == 0 && m0 + r < p.M) {
+  // The normalised rows are kept for the backward pass.  Every column-tile block of a row block holds the same rows, so
+  // each stores only ITS share of the 16 column chunks (16 / tiles_n of them) instead of the tn == 0 blocks storing whole
+  // rows: 64 KB per row block spread over all of its blocks -- those few blocks were the launch's long pole.
+  if (PRO != 0 && m0 + r < p.M) {
     const long ro = ni * p.act_ns + (long)(m0 + r) * HID + kb;
-    if (G.xh_out) {
+    const int gsz = 16 / tiles_n, g0 = tn * gsz;               // this block's chunks: [g0, g0 + gsz) (tiles_n is 8 or 16)
 #pragma unroll
-      for (int c = 0; c < CW; ++c) st4(G.xh_out + ro + 16 * c, xh[c]);
+    for (int c = 0; c < CW; ++c) {
+      const int gc = ks * CW + c;                              // (wave-uniform)
+      if (gc >= g0 && gc < g0 + gsz) {
+        if (G.xh_out) st4(G.xh_out + ro + 16 * c, xh[c]);
+        if (G.h_out) st4(G.h_out + ro + 16 * c, av[c]);
+      }
     }
-    if (G.h_out) {
-#pragma unroll
-      for (int c = 0; c < CW; ++c) st4(G.h_out + ro + 16 * c, av[c]);
-    }
-    if (G.rstd_out && ks == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
+    if (G.rstd_out && tn == 0 && ks == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
   }
   // ---- 4. second layer: this wave's rows x the block's 16 NT columns over its K range (W tiles from LDS)
   f32x4 acc[NT];
