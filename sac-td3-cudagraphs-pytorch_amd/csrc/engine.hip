@@ -381,7 +381,23 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   snprintf(inst, sizeof(inst), "k_tn<%d>.%s", kt, name);
   g.tiles = tiles;
   if (g.pk_blocks) by += 12.0 * (g.pk.n0 + g.pk.n1);
-  const dim3 grid((unsigned)(tiles + g.pk_blocks), 1, (unsigned)nets);
+  {   // what is not a GEMM tile goes to riding blocks (see TnArgs::fin)
+    AdamRedArgs& r = g.fin;
+    r = AdamRedArgs{};
+    r.s_off = -1;
+    for (int i = 0; i < g.nprob; ++i) {
+      const TnProb& q = g.pr[i];
+      for (int f = 0; f < q.nfin; ++f) { r.vec[r.nvec].off = q.fin_off[f]; r.vec[r.nvec].slot = q.fin_slot[f]; r.vec[r.nvec].nblk = q.fin_nblk[f]; ++r.nvec; }
+      if (q.fin_s_off >= 0) { r.s_off = q.fin_s_off; r.s_nblk = q.fin_s_nblk; }
+    }
+    r.nets = nets; r.g_ns = g.g_ns; r.G = g.G;
+    r.apply = g.apply; r.P = g.P; r.Mo = g.Mo; r.Vo = g.Vo; r.T = g.T; r.tau = g.tau; r.adam = g.adam; r.b1 = g.b1; r.b2 = g.b2; r.eps = g.eps;
+    r.part = g.part; r.pstride = g.pstride; r.part_s = g.part_s;
+    r.loss_part = g.loss_part; r.loss_n = g.loss_n; r.loss_stride = g.loss_stride; r.loss_off = g.loss_off; r.loss_scale = g.loss_scale;
+    r.loss_dst = g.loss_dst; r.tick = g.tick;
+    g.fin_blocks = 4 * r.nvec + 1;
+  }
+  const dim3 grid((unsigned)(tiles + g.pk_blocks + g.fin_blocks), 1, (unsigned)nets);
   if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
   if (kt == 2) hipLaunchKernelGGL(k_tn<2>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(k_tn<1>, grid, dim3(256), 0, s, g);

@@ -1020,6 +1020,92 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nn64(NnArgs p) {        // dX[
   }
 }
 
+// Sum of the split-M partial slabs + the vector gradients the row kernels left as per-row-block partials, then the
+// optimiser step of torch.optim.Adam (agents/agent.py:236,286) and the Polyak update of the same element (agents/agent.py:328).
+// Sources by offset range: `vec` ranges come from part[net][blk][slot][256] summed over the row blocks (16 threads per
+// float4, DPP-reduced), one scalar from part_s[net][blk][0], everything else from the S <= 8 slabs.  Sums run in a fixed
+// order, so replays are bit-reproducible.
+struct AdamRedVec { int off; int slot; int nblk; };
+struct AdamRedArgs {
+  const float* Gp; int S; int nets; long g_ns;           // slabs [S][nets][g_ns]
+  float* G;                                              // gradient arena (always written)
+  int apply; float* P; float* Mo; float* Vo; float* T; float tau;
+  const float* adam; float b1, b2, eps;
+  AdamRedVec vec[5]; int nvec;                           // 256-wide vectors finalised from row-block partials (nblk blocks each)
+  const float* part; int pstride;
+  int s_off; int s_nblk; const float* part_s;            // one scalar element (critic head bias), s_off < 0: none
+  const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
+};
+__device__ __forceinline__ void adam_red_commit(const AdamRedArgs& a, long off, float4 g, float4 w, float4 m, float4 v, float4 tt, float step, float sq2) {
+  st4(a.G + off, g);
+  if (a.apply) {
+    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
+    m = m + (g - m) * omb1;
+    v = v * a.b2 + g * g * omb2;
+    w.x -= step * (m.x / (sqrtf(v.x) / sq2 + a.eps)); w.y -= step * (m.y / (sqrtf(v.y) / sq2 + a.eps));
+    w.z -= step * (m.z / (sqrtf(v.z) / sq2 + a.eps)); w.w -= step * (m.w / (sqrtf(v.w) / sq2 + a.eps));
+    st4(a.Mo + off, m); st4(a.Vo + off, v); st4(a.P + off, w);
+    if (a.T) st4(a.T + off, tt + (w - tt) * a.tau);
+  }
+}
+// The "tail" blocks of a gradient finalisation: block `rel` < 4 nvec = one quarter of a 256-wide vector gradient (float4 column
+// (t >> 4) + 16 quarter; 16 threads share its row-block partials and DPP-reduce them); block 4 nvec = the scalar element
+// (critic head bias) + the loss finalisation + the counter tick.  Used by k_adam_red and, as riding blocks, by k_tn -- whose
+// tile blocks then do nothing but their GEMM tile and its optimiser step.
+__device__ __forceinline__ void adam_red_tail_body(const AdamRedArgs& a, int rel, int net) {
+  const int t = threadIdx.x;
+  const float step = a.apply ? a.adam[0] : 0.f, sq2 = a.apply ? a.adam[1] : 1.f;
+  if (rel < 4 * a.nvec) {
+    const int e = rel >> 2, quarter = rel & 3;
+    int voff = a.vec[0].off, vslot = a.vec[0].slot, nb = a.vec[0].nblk;
+    if (e == 1) { voff = a.vec[1].off; vslot = a.vec[1].slot; nb = a.vec[1].nblk; }
+    if (e == 2) { voff = a.vec[2].off; vslot = a.vec[2].slot; nb = a.vec[2].nblk; }
+    if (e == 3) { voff = a.vec[3].off; vslot = a.vec[3].slot; nb = a.vec[3].nblk; }
+    if (e == 4) { voff = a.vec[4].off; vslot = a.vec[4].slot; nb = a.vec[4].nblk; }
+    const int c4 = (t >> 4) + 16 * quarter, sub = t & 15;
+    const long off = net * a.g_ns + voff + 4 * c4;
+    float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
+    if (a.apply && sub == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+    const float* pp = a.part + ((long)net * a.pstride * NSLOT + vslot) * HID + 4 * c4;
+    float4 g = f4(0.f);
+    for (int blk = sub; blk < nb; blk += 64) {             // 4 independent requests per trip
+      const float4 v0 = ld4(pp + (long)blk * NSLOT * HID), v1 = ld4(pp + (long)min(blk + 16, nb - 1) * NSLOT * HID);
+      const float4 v2 = ld4(pp + (long)min(blk + 32, nb - 1) * NSLOT * HID), v3 = ld4(pp + (long)min(blk + 48, nb - 1) * NSLOT * HID);
+      g = g + v0;
+      if (blk + 16 < nb) g = g + v1;
+      if (blk + 32 < nb) g = g + v2;
+      if (blk + 48 < nb) g = g + v3;
+    }
+    g.x = row16_sum(g.x); g.y = row16_sum(g.y); g.z = row16_sum(g.z); g.w = row16_sum(g.w);
+    if (sub == 0) adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
+    return;
+  }
+  if (t >= 64) return;
+  // scalar element (+ the 3 padding floats behind it), then block-level extras by net 0
+  const bool extras = net == 0;
+  float loss_acc = 0.f; int tick_v = 0;
+  if (extras) {
+    if (a.loss_dst) for (int k = t; k < a.loss_n; k += 64) loss_acc += a.loss_part[(long)k * a.loss_stride + a.loss_off];
+    if (t == 0 && a.tick) tick_v = *a.tick;
+  }
+  if (a.s_off >= 0) {
+    const long off = net * a.g_ns + a.s_off;
+    float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
+    if (a.apply && t == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+    float sg = 0.f;
+    for (int blk = t; blk < a.s_nblk; blk += 64) sg += a.part_s[((long)net * a.pstride + blk) * 2];
+    sg = wave_sum(sg);
+    if (t == 0) adam_red_commit(a, off, make_float4(sg, 0.f, 0.f, 0.f), w, m, v, tt, step, sq2);
+  }
+  if (extras) {
+    if (a.loss_dst) {
+      const float sl = wave_sum(loss_acc);
+      if (t == 0) *a.loss_dst = sl * a.loss_scale;
+    }
+    if (t == 0 && a.tick) *a.tick = tick_v + 1;
+  }
+}
+
 // agents/agent.py:328-331: t <- t + tau (p - t) over up to two arenas; `block` of `nblocks` blocks of 256 threads
 struct PolyakArgs { float* t0; const float* p0; long n0; float* t1; const float* p1; long n1; float tau; };
 __device__ __forceinline__ void polyak_body(const PolyakArgs& a, unsigned block, unsigned nblocks) {
@@ -1055,6 +1141,10 @@ struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16
   // `pk_blocks` more blocks (net 0, after the `tiles` GEMM blocks) run a Polyak update of an arena this launch does not
   // otherwise touch (TD3: the actor target in the iterations that have no actor update, agents/agent.py:329-331)
   int tiles; int pk_blocks; PolyakArgs pk;
+  // ... and `fin_blocks` more (after those, every net) finalise what is not a GEMM tile: the vector gradients from the row
+  // kernels' partials, the scalar head-bias gradient, the loss and the counter tick (adam_red_tail_body).  Tile blocks that also
+  // did this (as the k-tile-0 blocks first did) were the launch's long pole: 2.5 memory round trips before their first MFMA.
+  int fin_blocks; AdamRedArgs fin;
 };
 
 struct AdamState { float w, m, v, t; };
@@ -1081,11 +1171,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float red[KT * 4 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
   __shared__ __attribute__((aligned(16))) float Xs[KT * 256 * YS];
-  __shared__ float cred[4 * 16 * 17];                    // [entry: 3 finalised vectors + the bias][16 partial groups][16 columns]
+  __shared__ float cred[16 * 17];                        // bias gradient: [16 partial groups][16 columns]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
-  if (p.pk_blocks && (int)blockIdx.x >= p.tiles) {          // (block-uniform) the riding Polyak update
-    if (net == 0) polyak_body(p.pk, blockIdx.x - p.tiles, p.pk_blocks);
+  if ((int)blockIdx.x >= p.tiles) {                         // (block-uniform) riding blocks
+    const int x = (int)blockIdx.x - p.tiles;
+    if (x < p.pk_blocks) { if (net == 0) polyak_body(p.pk, x, p.pk_blocks); }
+    else adam_red_tail_body(p.fin, x - p.pk_blocks, net);
     return;
   }
   int pi = 0;
@@ -1101,8 +1193,6 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   const int ecol = k0 + 16 * min(wave, KT - 1) + (lane & 15);
   AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
   STAMP(0);
-  // Requests go out in the order main operands -> optimiser state -> vector-gradient partials, so that the waits the
-  // partial-sum loops contain fall under the latency of the operand fetch instead of in front of it.
   // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
   const float* dYn = q.dY + net * q.dy_ns;
   const float* Xn = q.X + net * q.x_ns;
@@ -1131,45 +1221,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       st[i] = adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + min(ecol, q.ldw - 1));
     }
   }
-  // k-tile-0 blocks also finalise the vector gradients of their 16 columns: request those operands and the
-  // optimiser state of the finalised elements now, so that the epilogue waits for nothing
+  // k-tile-0 blocks also produce the bias gradient of their 16 columns (column sums of dY, collected from the LDS tile in the
+  // main loop): wave 3, lanes 0 .. 15 commit it; its optimiser state is requested now
   const int fcol = t & 15, fpart = t >> 4, fn = n0 + fcol;         // (column, partial-group) of this thread
-  float fsum[3] = {0.f, 0.f, 0.f}, ssum = 0.f;
-  AdamState fstate = sv, sst = sv;
+  const bool want_bias = tk == 0 && q.b_off >= 0;
+  AdamState fstate = sv;
   long foff = -1;
-  if (tk == 0) {
-#pragma unroll
-    for (int e = 0; e < 3; ++e)
-      if (e < q.nfin && fn < q.N) {
-        const int nb = q.fin_nblk[e];
-        const float* pp = p.part + ((long)net * p.pstride * NSLOT + q.fin_slot[e]) * HID + fn;
-        for (int blk = fpart; blk < nb; blk += 64) {       // 4 independent requests per trip (one trip up to B = 1024)
-          const float v0 = pp[(long)blk * NSLOT * HID], v1 = pp[(long)min(blk + 16, nb - 1) * NSLOT * HID];
-          const float v2 = pp[(long)min(blk + 32, nb - 1) * NSLOT * HID], v3 = pp[(long)min(blk + 48, nb - 1) * NSLOT * HID];
-          fsum[e] += (v0 + (blk + 16 < nb ? v1 : 0.f)) + ((blk + 32 < nb ? v2 : 0.f) + (blk + 48 < nb ? v3 : 0.f));
-        }
-      }
-    // wave 3, lane (entry = lane >> 4, column = lane & 15), commits one finalised element: entries 0..2 are the vector
-    // gradients, entry 3 the bias gradient (column sums of dY, collected from the LDS tile in the main loop);
-    // wave 0 has the weight tile, wave 1 the scalar entry, wave 2 block 0's extras
-    if (wave == 3) {
-      const int e = lane >> 4;
-      const bool has = e < 3 ? e < q.nfin : q.b_off >= 0;
-      const int eoff = e == 0 ? q.fin_off[0] : (e == 1 ? q.fin_off[1] : (e == 2 ? q.fin_off[2] : q.b_off));
-      if (has && fn < q.N) { foff = nbase + eoff + fn; fstate = adam_fetch(p, foff); }
-    }
-    if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
-      for (int blk = lane; blk < q.fin_s_nblk; blk += 64) ssum += p.part_s[((long)net * p.pstride + blk) * 2];
-      if (lane == 0) sst = adam_fetch(p, nbase + q.fin_s_off);
-    }
-  }
-  // block 0's extras (loss finalisation, counter tick): operands requested here as well
-  const bool extras = blockIdx.x == 0 && net == 0 && wave == 2;
-  float loss_acc = 0.f; int tick_v = 0;
-  if (extras) {
-    if (p.loss_dst) for (int i = lane; i < p.loss_n; i += 64) loss_acc += p.loss_part[(long)i * p.loss_stride + p.loss_off];
-    if (lane == 0 && p.tick) tick_v = *p.tick;
-  }
+  if (want_bias && wave == 3 && lane < 16 && fn < q.N) { foff = nbase + q.b_off + fn; fstate = adam_fetch(p, foff); }
   for (int mb = 0; mb < p.M; mb += 256) {
     if (mb) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -1197,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
         MFMA4(acc[kt], a, b);
       }
     }
-    if (tk == 0 && q.b_off >= 0) {
+    if (want_bias) {
       const int col = t & 15, part = t >> 4;
 #pragma unroll
       for (int i = 0; i < 16; ++i) asum += Ys[(part * 16 + i) * YS + col];
@@ -1207,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   // sum the 4 waves' accumulators of every tile (split-M); wave kt gets the total of tile kt
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) st4(red + ((kt * 4 + wave) * 64 + lane) * 4, make_float4(acc[kt][0], acc[kt][1], acc[kt][2], acc[kt][3]));
+  if (want_bias) cred[fpart * 17 + fcol] = asum;
   __syncthreads();
   STAMP(3);
   if (wave < KT && ecol < q.ldw) {
@@ -1219,32 +1278,13 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       if (row < q.N) adam_commit(p, nbase + q.w_off + (long)row * q.ldw + ecol, ecol < q.K ? o[i] : 0.f, st[i], step, sq2);
     }
   }
-  if (tk == 0) {
-    // one LDS pass for all four entries (a barrier pair per entry was most of this epilogue)
+  if (foff >= 0) {
+    float v = 0.f;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) cred[(e * 16 + fpart) * 17 + fcol] = fsum[e];
-    cred[(3 * 16 + fpart) * 17 + fcol] = asum;
-    __syncthreads();
-    if (wave == 3 && foff >= 0) {
-      const float* c = cred + (lane >> 4) * 16 * 17 + fcol;
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v += c[i * 17];
-      adam_commit(p, foff, v, fstate, step, sq2);
-    }
-    if (q.fin_s_off >= 0 && tn == 0 && wave == 1) {
-      const float s = wave_sum(ssum);
-      if (lane == 0) adam_commit(p, nbase + q.fin_s_off, s, sst, step, sq2);
-    }
+    for (int i = 0; i < 16; ++i) v += cred[i * 17 + fcol];
+    adam_commit(p, foff, v, fstate, step, sq2);
   }
   STAMP(4);
-  if (extras) {
-    if (p.loss_dst) {
-      const float s = wave_sum(loss_acc);
-      if (lane == 0) *p.loss_dst = s * p.loss_scale;
-    }
-    if (lane == 0 && p.tick) *p.tick = tick_v + 1;
-  }
 }
 
 // ---- large-batch form of the weight gradients (M >= 1024).  k_tn's 16 x 16 tiles make every block re-read a [M][16]
@@ -1458,105 +1498,30 @@ __global__ __launch_bounds__(256) void k_tn64(Tn64Args p) {
   STAMP(3);
 }
 
-// Sum of the split-M partial slabs + the vector gradients the row kernels left as per-row-block partials, then the
-// optimiser step of torch.optim.Adam (agents/agent.py:236,286) and the Polyak update of the same element (agents/agent.py:328).
-// Sources by offset range: `vec` ranges come from part[net][blk][slot][256] summed over the row blocks (16 threads per
-// float4, DPP-reduced), one scalar from part_s[net][blk][0], everything else from the S <= 8 slabs.  Sums run in a fixed
-// order, so replays are bit-reproducible.
-struct AdamRedVec { int off; int slot; int nblk; };
-struct AdamRedArgs {
-  const float* Gp; int S; int nets; long g_ns;           // slabs [S][nets][g_ns]
-  float* G;                                              // gradient arena (always written)
-  int apply; float* P; float* Mo; float* Vo; float* T; float tau;
-  const float* adam; float b1, b2, eps;
-  AdamRedVec vec[5]; int nvec;                           // 256-wide vectors finalised from row-block partials (nblk blocks each)
-  const float* part; int pstride;
-  int s_off; int s_nblk; const float* part_s;            // one scalar element (critic head bias), s_off < 0: none
-  const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
-};
-__device__ __forceinline__ void adam_red_commit(const AdamRedArgs& a, long off, float4 g, float4 w, float4 m, float4 v, float4 tt, float step, float sq2) {
-  st4(a.G + off, g);
-  if (a.apply) {
-    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
-    m = m + (g - m) * omb1;
-    v = v * a.b2 + g * g * omb2;
-    w.x -= step * (m.x / (sqrtf(v.x) / sq2 + a.eps)); w.y -= step * (m.y / (sqrtf(v.y) / sq2 + a.eps));
-    w.z -= step * (m.z / (sqrtf(v.z) / sq2 + a.eps)); w.w -= step * (m.w / (sqrtf(v.w) / sq2 + a.eps));
-    st4(a.Mo + off, m); st4(a.Vo + off, v); st4(a.P + off, w);
-    if (a.T) st4(a.T + off, tt + (w - tt) * a.tau);
-  }
-}
 // grid = (main blocks + 4 nvec vector blocks + 1 scalar block, nets); main blocks = ceil(g_ns / 1024)
 __global__ __launch_bounds__(256) void k_adam_red(AdamRedArgs a) {
   const int net = blockIdx.y, t = threadIdx.x;
   const int main_blocks = (int)((a.g_ns / 4 + 255) / 256);
-  const float step = a.apply ? a.adam[0] : 0.f, sq2 = a.apply ? a.adam[1] : 1.f;
-  const bool extras = blockIdx.x == 0 && net == 0 && t < 64;
-  float loss_acc = 0.f; int tick_v = 0;
-  if (extras) {
-    if (a.loss_dst) for (int k = t; k < a.loss_n; k += 64) loss_acc += a.loss_part[(long)k * a.loss_stride + a.loss_off];
-    if (t == 0 && a.tick) tick_v = *a.tick;
-  }
   const int bx = blockIdx.x;
-  if (bx < main_blocks) {
-    // slab-sourced elements: one float4 per thread (the vector ranges and the scalar's float4 belong to the blocks below)
-    const long i = ((long)bx * 256 + t) * 4;
-    bool mine = i < a.g_ns && !(a.s_off >= 0 && i == a.s_off);
+  if (bx >= main_blocks) { adam_red_tail_body(a, bx - main_blocks, net); return; }
+  const float step = a.apply ? a.adam[0] : 0.f, sq2 = a.apply ? a.adam[1] : 1.f;
+  // slab-sourced elements: one float4 per thread (the vector ranges and the scalar's float4 belong to the tail blocks)
+  const long i = ((long)bx * 256 + t) * 4;
+  bool mine = i < a.g_ns && !(a.s_off >= 0 && i == a.s_off);
 #pragma unroll
-    for (int e = 0; e < 5; ++e)
-      if (e < a.nvec && i >= a.vec[e].off && i < a.vec[e].off + HID) mine = false;
-    if (mine) {
-      const long off = net * a.g_ns + i;
-      float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
-      if (a.apply) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
-      float4 gs[8];
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) gs[sl] = ld4(a.Gp + ((long)min(sl, a.S - 1) * a.nets + net) * a.g_ns + i);   // all requests first
-      float4 g = gs[0];
-#pragma unroll
-      for (int sl = 1; sl < 8; ++sl) if (sl < a.S) g = g + gs[sl];
-      adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
-    }
-  } else if (bx < main_blocks + 4 * a.nvec) {
-    // one quarter of a 256-wide vector gradient: float4 column (t >> 4) + 16 quarter, 16 threads share its row-block partials
-    const int e = (bx - main_blocks) >> 2, quarter = (bx - main_blocks) & 3;
-    int voff = a.vec[0].off, vslot = a.vec[0].slot, nb = a.vec[0].nblk;
-    if (e == 1) { voff = a.vec[1].off; vslot = a.vec[1].slot; nb = a.vec[1].nblk; }
-    if (e == 2) { voff = a.vec[2].off; vslot = a.vec[2].slot; nb = a.vec[2].nblk; }
-    if (e == 3) { voff = a.vec[3].off; vslot = a.vec[3].slot; nb = a.vec[3].nblk; }
-    if (e == 4) { voff = a.vec[4].off; vslot = a.vec[4].slot; nb = a.vec[4].nblk; }
-    const int c4 = (t >> 4) + 16 * quarter, sub = t & 15;
-    const long off = net * a.g_ns + voff + 4 * c4;
+  for (int e = 0; e < 5; ++e)
+    if (e < a.nvec && i >= a.vec[e].off && i < a.vec[e].off + HID) mine = false;
+  if (mine) {
+    const long off = net * a.g_ns + i;
     float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
-    if (a.apply && sub == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
-    const float* pp = a.part + ((long)net * a.pstride * NSLOT + vslot) * HID + 4 * c4;
-    float4 g = f4(0.f);
-    for (int blk = sub; blk < nb; blk += 64) {             // 4 independent requests per trip
-      const float4 v0 = ld4(pp + (long)blk * NSLOT * HID), v1 = ld4(pp + (long)min(blk + 16, nb - 1) * NSLOT * HID);
-      const float4 v2 = ld4(pp + (long)min(blk + 32, nb - 1) * NSLOT * HID), v3 = ld4(pp + (long)min(blk + 48, nb - 1) * NSLOT * HID);
-      g = g + v0;
-      if (blk + 16 < nb) g = g + v1;
-      if (blk + 32 < nb) g = g + v2;
-      if (blk + 48 < nb) g = g + v3;
-    }
-    g.x = row16_sum(g.x); g.y = row16_sum(g.y); g.z = row16_sum(g.z); g.w = row16_sum(g.w);
-    if (sub == 0) adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
-  } else if (a.s_off >= 0 && t < 64) {
-    // the scalar element (critic head bias) and the 3 padding floats behind it
-    const long off = net * a.g_ns + a.s_off;
-    float4 w = f4(0.f), m = f4(0.f), v = f4(0.f), tt = f4(0.f);
-    if (a.apply && t == 0) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
-    float sg = 0.f;
-    for (int blk = t; blk < a.s_nblk; blk += 64) sg += a.part_s[((long)net * a.pstride + blk) * 2];
-    sg = wave_sum(sg);
-    if (t == 0) adam_red_commit(a, off, make_float4(sg, 0.f, 0.f, 0.f), w, m, v, tt, step, sq2);
-  }
-  if (extras) {
-    if (a.loss_dst) {
-      const float s = wave_sum(loss_acc);
-      if (t == 0) *a.loss_dst = s * a.loss_scale;
-    }
-    if (t == 0 && a.tick) *a.tick = tick_v + 1;
+    if (a.apply) { w = ld4(a.P + off); m = ld4(a.Mo + off); v = ld4(a.Vo + off); if (a.T) tt = ld4(a.T + off); }
+    float4 gs[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) gs[sl] = ld4(a.Gp + ((long)min(sl, a.S - 1) * a.nets + net) * a.g_ns + i);   // all requests first
+    float4 g = gs[0];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) if (sl < a.S) g = g + gs[sl];
+    adam_red_commit(a, off, g, w, m, v, tt, step, sq2);
   }
 }
 

@@ -63,7 +63,7 @@ int main() {
     q0.nfin = 3; q0.fin_slot[0] = 0; q0.fin_off[0] = b2 + 256; q0.fin_slot[1] = 1; q0.fin_off[1] = b2 + 512; q0.fin_slot[2] = 2; q0.fin_off[2] = b2 + 768; q0.fin_s_off = b2 + 768 + 256; q0.fin_s_nblk = 16; q0.fin_nblk[0] = q0.fin_nblk[1] = q0.fin_nblk[2] = 16; q0.tile0 = 0;
     TnProb q1{}; q1.dY = Y; q1.ldy = 256; q1.dy_ns = B * 256; q1.N = 256; q1.X = X; q1.ldx = ldc; q1.x_ns = 0; q1.K = o + a; q1.w_off = W1; q1.ldw = 16; q1.b_off = b1;
     q1.nfin = 2; q1.fin_slot[0] = 3; q1.fin_off[0] = g1; q1.fin_slot[1] = 4; q1.fin_off[1] = be1; q1.fin_s_off = -1; q1.fin_nblk[0] = q1.fin_nblk[1] = 16; q1.tile0 = 256;
-    g.pr[0] = q0; g.pr[1] = q1; g.apply = 1; g.P = P; g.Mo = Mo; g.Vo = Vo; g.T = T; g.tau = 0.005f; g.adam = adam; g.b1 = 0.9f; g.b2 = 0.999f; g.eps = 1e-8f;
+    g.pr[0] = q0; g.pr[1] = q1; g.tiles = 272; g.apply = 1; g.P = P; g.Mo = Mo; g.Vo = Vo; g.T = T; g.tau = 0.005f; g.adam = adam; g.b1 = 0.9f; g.b2 = 0.999f; g.eps = 1e-8f;
     g.part = part; g.pstride = 16; g.part_s = ps; g.loss_part = ps; g.loss_n = 32; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.f / B; g.loss_dst = adam + 2;
     double us = graph_us(s, [&] { hipLaunchKernelGGL(k_tn<1>, dim3(272, 1, 2), dim3(256), 0, s, g); }, 20, 50);
     show("k_tn critics (+Adam)", us, 5);
