@@ -679,6 +679,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
   const bool clip = c.clip_norm > 0.f;
+  const bool small_head = e->nh <= 8 && e->a <= 8 && !(e->tune_rows4 & 4);      // single-wave 4-row head backward (k_actor_head_bwd_s)
   e->node_role = (j & 1) ? "actor1/policy" : "actor0/policy";
   if (!head_done) {  // a_pi, logp = pi(s) with stores for the backward pass
     const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
@@ -727,8 +728,10 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.xh2 = e->a_xh2; h.rstd2 = e->a_rs2; h.h2 = e->a_h2;
     h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
     h.part = e->part;
-    LAUNCH("k_actor_head_bwd", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
-           k_actor_head_bwd, dim3(e->nblk), dim3(256), h);
+    if (small_head) LAUNCH("k_actor_head_bwd_s<4>", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
+                           k_actor_head_bwd_s<4>, dim3(e->nblk4), dim3(64), h);
+    else LAUNCH("k_actor_head_bwd", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
+                k_actor_head_bwd, dim3(e->nblk), dim3(256), h);
   }
   {
     NnArgs g{};
@@ -747,7 +750,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
     g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
     g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
-    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, e->nblk); tn_fin(g.pr[1], 1, e->La.be2, e->nblk); }
+    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, small_head ? e->nblk4 : e->nblk); tn_fin(g.pr[1], 1, e->La.be2, small_head ? e->nblk4 : e->nblk); }
     g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, e->X, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
     if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;

@@ -2233,6 +2233,81 @@ __global__ __launch_bounds__(256) void k_actor_head_bwd(ActorHeadBwd p) {
   block_colsum<16>(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
 }
 
+// Narrow heads (nh <= 8), as k_actor_tail_s: a row lives in ONE wave (RPB rows x 16 threads = 64 threads per block).  Lane n of
+// a row computes head-output gradient du[n] itself (lanes a .. 2a-1 redo their element's arithmetic for the log-std half instead
+// of fetching it across lanes), du[n] reaches the row's other lanes by DPP row broadcast, dh2 = du Wh is nh FMAs per column on
+// the vector ALU, and the dgamma / dbeta partials are summed over the block's rows through wave-local LDS: no MFMA, no block barrier.
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actor_head_bwd_s(ActorHeadBwd p) {
+  __shared__ __attribute__((aligned(16))) float cs[2 * RPB * HID];
+  const int t = threadIdx.x, row = t >> 4, sub = t & 15;
+  const int b = blockIdx.x * RPB + row, bc = min(b, p.B - 1);
+  const bool valid = b < p.B;
+  const int nh = p.L.nh;                         // <= 8, and a <= 8
+  const float* Wh = p.P + p.L.Wh;
+  // loads first
+  const long ro = (long)bc * HID;
+  const Row16 hh = row_ld(p.h2 + ro, sub), xh = row_ld(p.xh2 + ro, sub);
+  Row16 g;
+  if (p.ln) g = row_ld(p.P + p.L.g2, sub);
+  const float rstd = p.ln ? p.rstd2[bc] : 1.f;
+  Row16 w[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) w[n] = row_ld(Wh + (long)min(n, nh - 1) * HID, sub);   // unconditional, row clamped
+  // lane `sub` < nh owns head output n = sub: action element j = n (mean half) or n - a (log-std half, SAC)
+  const bool second = sub >= p.a;
+  const int j0 = min(second ? sub - p.a : sub, p.a - 1);
+  const float* tgr = p.tg + (long)bc * 4 * p.a4;
+  float la = p.sac ? *p.log_alpha : 0.f;
+  float o_dA = p.dA[(long)bc * p.ldA + j0], o_dA1 = p.nq == 2 ? p.dA[p.dA_ns + (long)bc * p.ldA + j0] : 0.f;
+  float o_sc = p.scale[j0], o_t0 = tgr[j0];
+  float o_t1 = 0.f, o_t2 = 0.f, o_e = 0.f;
+  if (p.sac) { o_t1 = tgr[p.a4 + j0]; o_t2 = tgr[2 * p.a4 + j0]; o_e = p.eps[(long)bc * p.a + j0]; }
+  PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
+  const float dlogp = p.sac ? expf(la) / (float)p.B : 0.f;
+  float d;                                        // du[sub]
+  {
+    const float dAj = o_dA + o_dA1, sc = o_sc;
+    float g_mean, g_raw = 0.f;
+    if (p.sac) {
+      const float tt = o_t0, sd = o_t1, yt = o_t2;
+      const float omy2 = 1.0f - yt * yt;
+      const float g0 = dAj * sc * omy2 + dlogp * (2.0f * sc * yt * omy2) / (sc * omy2 + 1e-6f);
+      g_mean = g0;
+      g_raw = (g0 * o_e * sd - dlogp) * 3.5f * (1.0f - tt * tt);
+    } else {
+      g_mean = dAj * sc * (1.0f - o_t0 * o_t0);
+    }
+    d = second ? g_raw : g_mean;
+    if (!valid || sub >= nh) d = 0.f;
+  }
+  // dh2[c] = sum_n du[n] Wh[n][c]
+  Row16 dh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dh.v[q] = f4(0.f);
+  auto add_n = [&](float dn, const Row16& wn) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dh.v[q] = dh.v[q] + wn.v[q] * dn;
+  };
+  row_pin(w[0]); add_n(dpp_mov<0x150>(d), w[0]);           // row_newbcast:n = lane n of every 16-lane row to all of its lanes
+  row_pin(w[1]); add_n(dpp_mov<0x151>(d), w[1]);
+  row_pin(w[2]); add_n(dpp_mov<0x152>(d), w[2]);
+  row_pin(w[3]); add_n(dpp_mov<0x153>(d), w[3]);
+  row_pin(w[4]); add_n(dpp_mov<0x154>(d), w[4]);
+  row_pin(w[5]); add_n(dpp_mov<0x155>(d), w[5]);
+  row_pin(w[6]); add_n(dpp_mov<0x156>(d), w[6]);
+  row_pin(w[7]); add_n(dpp_mov<0x157>(d), w[7]);           // (lanes >= nh hold d = 0: their clamped weight rows add nothing)
+  if (valid && sub < nh) p.du[(long)b * p.ldu + sub] = d;
+  Row16 dy, vals[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(dh.v[q], hh.v[q]);
+  const Row16 dz = ln_bwd(dy, xh, rstd, g, p.ln);
+  if (valid) row_st(p.dz2 + (long)b * HID, sub, dz);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
+  block_colsum<RPB>(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
+}
+
 // ------------------------------------------------------------------------------------------------ optimiser
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; long n;   // n multiple of 4
