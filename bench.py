@@ -484,7 +484,7 @@ def main():
         }
         if args.dry_run_ranks:
             out.update(dry_run=True, value=None, note="no GPU work was done: rank launching / rendezvous / aggregation rehearsal only")
-        elif not args.timed_only:
+        elif not args.timed_only and world == 1:     # N > 1 lines carry the timed region only (roofline / cpu_baseline: N = 1)
             extras(out, eng, w, args, local, world)
         print(json.dumps(out), flush=True)
     if dist:
@@ -531,7 +531,7 @@ def extras(out, eng, w, args, local, world):
         eng.step(i % 3 == 0)
     eng.sync()
     out["loop_with_acting_per_s"] = 600 / (time.perf_counter() - tp)
-    if world != 1 or args.no_baselines:
+    if args.no_baselines:
         eng.close()
         return
     # Seed sweeps are the reference's unit of work (spawner.py: one job per seed) and one learner leaves most of an

@@ -89,6 +89,7 @@ struct sactd3_engine {
   int nq_actor = 2;            // critics evaluated in the actor update (SAC 2, TD3 1)
   int nblk = 0, nblk4 = 0;     // row-kernel blocks for B rows: 16 rows each (MFMA-using tails) / 4 rows each (plain row kernels)
   AlphaArgs pending_alpha{}; bool alpha_pending = false;   // a temperature step deferred into the next update's trunk launch (enqueue time only)
+  bool alpha_tick_owed = false;   // ... deferred across an ITERATION boundary (period graphs): its counter tick is made up by the next critic update
   int maxn = 0;                // rows accepted by predict
   int num_cus = 256;
   int stage_rows = 0;
@@ -305,7 +306,7 @@ static int launch_nn(sactd3_engine* e, hipStream_t s, const char* name, const Nn
 #endif
 #define TN64_KERNEL (k_tn64<TN64_CFG>)
 // Large batches: split-M GEMM into partial slabs (k_tn64) + slab sum / vector gradients / Adam / Polyak (k_adam_red).
-static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const TnArgs& g, int nets) {
+static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const TnArgs& g, int nets, int tick_extra = 0) {
   Tn64Args a{};
   a.nprob = g.nprob; a.M = g.M; a.nets = nets; a.Gp = e->Gp; a.g_ns = nets > 1 ? g.g_ns : (long)e->La.size;
   AdamRedArgs r{};
@@ -341,7 +342,7 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
   r.apply = g.apply; r.P = g.P; r.Mo = g.Mo; r.Vo = g.Vo; r.T = g.T; r.tau = g.tau; r.adam = g.adam; r.b1 = g.b1; r.b2 = g.b2; r.eps = g.eps;
   r.part = g.part; r.pstride = g.pstride; r.part_s = g.part_s;
   r.loss_part = g.loss_part; r.loss_n = g.loss_n; r.loss_stride = g.loss_stride; r.loss_off = g.loss_off; r.loss_scale = g.loss_scale;
-  r.loss_dst = g.loss_dst; r.tick = g.tick;
+  r.loss_dst = g.loss_dst; r.tick = g.tick; r.tick_extra = tick_extra;
   const dim3 grid((unsigned)((size / 4 + 255) / 256 + 4 * r.nvec + 1), (unsigned)nets);
   LAUNCH(g.apply ? (g.T ? "k_adam_red.sum+adam+polyak" : "k_adam_red.sum+adam") : "k_adam_red.sum", 0.0,
          nets * (double)size * (4.0 * S + 4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)), k_adam_red, grid, dim3(256), r);
@@ -349,13 +350,13 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
   return 0;
 }
 
-static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets) {
+static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets, int tick_extra = 0) {
   if (g.M >= BIG_BATCH && e->Gp && !e->tune_tn_kt) {
     // the split-M form pays an extra node (k_adam_red): taken when the launch has enough 64 x 32 tiles to fill the chip with
     // long slices (the critics' 168 at Humanoid: 25.6 -> 18.6 us); the actor's 88 tiles gain nothing (14.3 vs 14.4 us)
     int tiles = 0;
     for (int i = 0; i < g.nprob; ++i) tiles += ((g.pr[i].N + TN64_N - 1) / TN64_N) * ((g.pr[i].ldw + TN64_K - 1) / TN64_K);
-    if (tiles * nets >= e->tune_tn64_min) return launch_tn64(e, s, name, g, nets);
+    if (tiles * nets >= e->tune_tn64_min) return launch_tn64(e, s, name, g, nets, tick_extra);
   }
   auto count = [&](int kt) {
     int tiles = 0;
@@ -394,7 +395,7 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
     r.apply = g.apply; r.P = g.P; r.Mo = g.Mo; r.Vo = g.Vo; r.T = g.T; r.tau = g.tau; r.adam = g.adam; r.b1 = g.b1; r.b2 = g.b2; r.eps = g.eps;
     r.part = g.part; r.pstride = g.pstride; r.part_s = g.part_s;
     r.loss_part = g.loss_part; r.loss_n = g.loss_n; r.loss_stride = g.loss_stride; r.loss_off = g.loss_off; r.loss_scale = g.loss_scale;
-    r.loss_dst = g.loss_dst; r.tick = g.tick;
+    r.loss_dst = g.loss_dst; r.tick = g.tick; r.tick_extra = tick_extra;
     g.fin_blocks = 4 * r.nvec + 1;
   }
   const dim3 grid((unsigned)(tiles + g.pk_blocks + g.fin_blocks), 1, (unsigned)nets);
@@ -571,6 +572,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
+  int ctr_owed = 0;
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
   {
@@ -584,20 +586,29 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     bool eps_ready = false;
     if (!td3 || mode == 1) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise_taken = &eps_ready; }
+    // a temperature step deferred from the previous iteration of the same graph (sactd3_step_period) rides in this launch; its
+    // tick of the noise counter is owed: this iteration's draws count one ahead and the critics' last kernel ticks by two
+    int owed = 0;
+    if (e->alpha_pending && e->alpha_tick_owed && in_kernel_gather) {
+      tk.alpha = &e->pending_alpha; e->alpha_pending = false; e->alpha_tick_owed = false;
+      owed = 1;
+      for (int i = 0; i < tk.nnoise; ++i) tk.noise[i].ctr_add += 1;
+    }
+    ctr_owed = owed;
     if (merge_policy) {
       // the policy sample of the first actor update: same actor parameters (the critic update does not touch them), the stream
       // counter one ahead (the critic update's last kernel bumps it before the actor update would have read it)
-      if (!td3) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, 1, B); tk.noise_taken = &eps_ready; }
+      if (!td3) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, 1 + owed, B); tk.noise_taken = &eps_ready; }
       tk.force_ks = 4;
       tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
     }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, merge_policy ? 2 : 1, 1, g, tk));
     ActorTail t = tail_args(e, merge_policy ? e->a_z2n : e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
-    t.eps_ready = eps_ready;
+    t.eps_ready = eps_ready; t.ctr_add = owed;
     if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
     if (merge_policy && tail_rows_per_block(t) == 4) {
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
+      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
       const int nb = (B + 3) / 4;
       LAUNCH("k_actor_tail_s2<4>", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
              k_actor_tail_s2<4>, dim3(2 * nb), dim3(64), t, t1, nb);
@@ -605,7 +616,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     } else if (merge_policy) {                  // (wide heads: the two tails as two launches of the general kernel)
       RCCHK(launch_tail(e, s, t));
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1; t1.eps_ready = eps_ready;
+      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;
       RCCHK(launch_tail(e, s, t1));
       if (policy_done) *policy_done = true;
     } else RCCHK(launch_tail(e, s, t));
@@ -663,7 +674,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       g.pk_blocks = (int)std::min<long>(64, (e->La.size / 4 + 255) / 256);
       if (actor_targ_done) *actor_targ_done = true;
     }
-    RCCHK(launch_tn(e, s, fused_polyak_targ ? (rides ? "dW+adam+polyak & actor-target polyak" : "dW+adam+polyak") : "dW+adam", g, 2));
+    RCCHK(launch_tn(e, s, fused_polyak_targ ? (rides ? "dW+adam+polyak & actor-target polyak" : "dW+adam+polyak") : "dW+adam", g, 2, ctr_owed));
   }
   return 0;
 }
@@ -673,7 +684,10 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
 // merge_next: produce the NEXT update's policy sample together with this update's temperature draw.
 // polyak_targ: (TD3, last actor update of a fused iteration) lerp the actor target towards the freshly stepped actor in the same
 // kernel that applies the step (agents/agent.py:331 after :286)
-static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false, float* polyak_targ = nullptr) {
+// defer_alpha: (last actor update of an iteration that is followed by another one in the same graph) leave the temperature step
+// to the next iteration's opening launch
+static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false, float* polyak_targ = nullptr,
+                                bool defer_alpha = false) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
@@ -801,6 +815,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     al.logp = e->logp_al; al.B = B; al.targ_ent = -(float)e->a; al.autotune = c.autotune; al.la = e->la; al.ctl = e->ctl;
     al.lr = c.log_alpha_lr; al.b1 = c.adam_beta1; al.b2 = c.adam_beta2; al.eps = c.adam_eps; al.tick = &e->ctl->noise_ctr;
     if (merge_next) { e->pending_alpha = al; e->alpha_pending = true; }   // rides in the next update's critic-trunk launch
+    else if (defer_alpha) { al.tick = nullptr; e->pending_alpha = al; e->alpha_pending = true; e->alpha_tick_owed = true; }
     else {
       LAUNCH("k_alpha_step", 0.0, 4.0 * B, k_alpha_step, dim3(1), dim3(256), al);
     }
@@ -822,7 +837,7 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 }
 
 // orchestrator.py:337-352 as one sequence
-static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak) {
+static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak, bool next_in_same_graph = false) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   e->node_role = "sample";
   if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
@@ -843,7 +858,9 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
       const bool last = j + 1 == n;
       float* pt = nullptr;
       if (actor_targ && last) { pt = e->Ta; actor_targ_done = true; }
-      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt));
+      // the last temperature step can wait for the next iteration's first launch when that launch is the fused-first-layer kind
+      const bool defer = last && next_in_same_graph && !td3 && e->o <= 64 && e->B < BIG_BATCH;
+      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer));
     }
   }
   if (actor_targ && !actor_targ_done) RCCHK(enqueue_polyak(e, s, false, true));
@@ -1380,7 +1397,8 @@ int sactd3_step_period(sactd3_engine* e) {
   const int n = e->cfg.actor_update_delay + 1;
   e->qnet_updates += n;
   return run_graph(e, G_PERIOD, [&](hipStream_t s) {
-    for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true));
+    for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n));
+    if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
     return 0;
   });
 }

@@ -1035,6 +1035,7 @@ struct AdamRedArgs {
   const float* part; int pstride;
   int s_off; int s_nblk; const float* part_s;            // one scalar element (critic head bias), s_off < 0: none
   const float* loss_part; int loss_n, loss_stride, loss_off; float loss_scale; float* loss_dst; int* tick;
+  int tick_extra;                                        // the counter advances by 1 + tick_extra (a deferred temperature step's tick)
 };
 __device__ __forceinline__ void adam_red_commit(const AdamRedArgs& a, long off, float4 g, float4 w, float4 m, float4 v, float4 tt, float step, float sq2) {
   st4(a.G + off, g);
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void adam_red_tail_body(const AdamRedArgs& a, int rel
       const float sl = wave_sum(loss_acc);
       if (t == 0) *a.loss_dst = sl * a.loss_scale;
     }
-    if (t == 0 && a.tick) *a.tick = tick_v + 1;
+    if (t == 0 && a.tick) *a.tick = tick_v + 1 + a.tick_extra;
   }
 }
 
