@@ -105,7 +105,8 @@ def test_no_serialised_operand_loads():
         if "k_rb_fill" in name:          # synthetic-data filler of the bench, not on any path
             continue
         assert "LWLWLW" not in seq, (name, seq)
-    # (mangled names: "4k_tnI" = the k_tn<KT> instances, "6k_tn64I" = k_tn64<...>, whose prologue requests two chunks of 4 + 2 float4)
-    for key, batch in (("k_nt64", 4), ("k_nt_wide", 16), ("4k_tnI", 16), ("6k_tn64I", 12), ("k_nn", 16), ("k_critic_tail", 32), ("k_actor_tail", 32)):
+    # (mangled names: "4k_tnI" = the k_tn<KT> instances, "6k_tn64I" = k_tn64<...>, whose prologue requests two chunks of 4 + 2 float4; "_Z4k_nn" = k_nn alone,
+    # "6k_nn64I" = the LDS-tiled k_nn64<...> instances: 4 to 6 float4 per chunk)
+    for key, batch in (("k_nt64", 4), ("k_nt_wide", 16), ("4k_tnI", 16), ("6k_tn64I", 12), ("_Z4k_nn", 16), ("6k_nn64I", 4), ("k_critic_tail", 32), ("k_actor_tail", 32)):
         hit = [s for n, s in seqs.items() if key in n]
         assert hit and all("L" * batch in s for s in hit), (key, hit)
