@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/sactd3.h"
@@ -115,11 +116,13 @@ struct sactd3_engine {
   float *part = nullptr, *part_s = nullptr, *part_sa = nullptr;   // column partials; scalar partials of the critic / actor updates
   float *p_x = nullptr, *p_z1 = nullptr, *p_z2 = nullptr, *p_act = nullptr;
   float *h_obs = nullptr, *h_act = nullptr;      // pinned predict staging
+  int* h_done = nullptr; int predict_calls = 0;  // pinned completion word of the acting tail / calls issued (see ActorTail::done_flag)
   float* h_stage[NSTAGE] = {}; int stage_next = 0, stage_used = 0;   // pinned staging slots of rb_extend
   float* h_batch = nullptr;                      // pinned [B][rec_f]
 
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
+  std::vector<hipGraphExec_t> predict_graphs;   // [explore][n]: the two launches of sactd3_predict, captured per row count
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
   int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0, tune_nn16 = 0;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
@@ -868,9 +871,13 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
 }
 
 template <class F>
-static int run_graph(sactd3_engine* e, int which, F&& enqueue) {
+static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue);
+template <class F>
+static int run_graph(sactd3_engine* e, int which, F&& enqueue) { return run_graph_slot(e, &e->graphs[which], &e->graph_nodes[which], enqueue); }
+template <class F>
+static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue) {
   if (!e->cfg.use_graphs) return enqueue(e->stream);
-  if (!e->graphs[which]) {
+  if (!*slot) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue(e->stream);
@@ -879,12 +886,12 @@ static int run_graph(sactd3_engine* e, int which, F&& enqueue) {
     if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipStreamEndCapture", he);
     size_t n = 0;
     HIPCHK(hipGraphGetNodes(g, nullptr, &n));
-    e->graph_nodes[which] = (int)n;
-    he = hipGraphInstantiate(&e->graphs[which], g, nullptr, nullptr, 0);
+    if (nodes) *nodes = (int)n;
+    he = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipGraphInstantiate", he);
   }
-  HIPCHK(hipGraphLaunch(e->graphs[which], e->stream));
+  HIPCHK(hipGraphLaunch(*slot, e->stream));
   return 0;
 }
 
@@ -927,6 +934,7 @@ void sactd3_destroy(sactd3_engine* e) {
   if (e->stream) (void)hipSetDevice(e->cfg.device_id);   // (a failed create may carry a device_id that was never valid)
   if (e->stream) hipStreamSynchronize(e->stream);
   for (auto& g : e->graphs) if (g) hipGraphExecDestroy(g);
+  for (auto& g : e->predict_graphs) if (g) hipGraphExecDestroy(g);
   for (auto ev : e->events) hipEventDestroy(ev);
   for (void* p : e->dev_allocs) hipFree(p);
   for (void* p : e->host_allocs) hipHostFree(p);
@@ -1010,6 +1018,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->p_x, (size_t)e->maxn * e->ldo)); RCCHK(dalloc(e, &e->p_z1, (size_t)e->maxn * HID));
   RCCHK(dalloc(e, &e->p_z2, (size_t)e->maxn * HID)); RCCHK(dalloc(e, &e->p_act, (size_t)e->maxn * e->a4));
   RCCHK(halloc(e, &e->h_obs, (size_t)e->maxn * e->ldo)); RCCHK(halloc(e, &e->h_act, (size_t)e->maxn * e->a4));
+  RCCHK(halloc(e, &e->h_done, 4));
   RCCHK(halloc(e, &e->h_batch, B * e->rec_f));
   for (int i = 0; i < NSTAGE; ++i) {
     RCCHK(halloc(e, &e->h_stage[i], (size_t)e->stage_rows * e->rec_f));
@@ -1408,33 +1417,56 @@ int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float
   USE_DEVICE(e);
   if (n < 1 || n > e->maxn) return e->fail(SACTD3_EINVAL, "predict: 1 <= n <= max_envs");
   const bool td3 = e->cfg.prefer_td3_over_sac;
-  HIPCHK(hipStreamSynchronize(e->stream));   // pinned staging is reused
+  // (the pinned staging is free: every call returns only after its own kernels have finished, see below)
   for (int i = 0; i < n; ++i) {
     memset(e->h_obs + (size_t)i * e->ldo, 0, sizeof(float) * e->ldo);
     memcpy(e->h_obs + (size_t)i * e->ldo, obs + (size_t)i * e->o, sizeof(float) * e->o);
   }
-  bool eps_ready = false;
   // The kernels read the observations from, and write the actions to, the pinned host buffers themselves (a few hundred
   // bytes over the host link): two kernels and one synchronisation per call, no copy commands, no separate counter kernel.
-  {
-    const TrunkGrp g{e->h_obs, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
-    TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
-    if (explore) { tk.nnoise = 1; tk.noise[0] = noise_job(e, SACTD3_SITE_PREDICT, 48u, 0, n); tk.noise_taken = &eps_ready; }
-    RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, tk));
+  // Nothing in the launches depends on the call but (n, explore): they are captured once per pair and replayed.
+  if (e->predict_graphs.empty()) e->predict_graphs.assign(2 * (size_t)(e->maxn + 1), nullptr);
+  RCCHK(run_graph_slot(e, &e->predict_graphs[(size_t)(explore ? 1 : 0) * (e->maxn + 1) + n], nullptr, [&](hipStream_t) {
+    bool eps_ready = false;
+    {
+      const TrunkGrp g{e->h_obs, e->Pa, e->p_z1, e->p_z2, nullptr, nullptr, nullptr};
+      TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+      if (explore) { tk.nnoise = 1; tk.noise[0] = noise_job(e, SACTD3_SITE_PREDICT, 48u, 0, n); tk.noise_taken = &eps_ready; }
+      RCCHK(enqueue_trunk(e, e->stream, e->ldo, e->o, n, e->La, 0, 1, 1, &g, tk));
+    }
+    const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
+    ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr);
+    t.eps_ready = eps_ready;
+    // the tail reads predict_ctr (its noise stream) and may only advance it itself when it is a single block: with more
+    // rows than one block holds, a late block could read the counter after block 0 has bumped it
+    const bool one_block = n <= tail_rows_per_block(t);
+    if (explore && one_block) t.tick = &e->ctl->predict_ctr;
+    if (one_block) { t.seq = &e->ctl->predict_seq; t.done_flag = e->h_done; }
+    RCCHK(launch_tail(e, e->stream, t));
+    if (explore && !one_block) {
+      hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }));
+  // completion: a single-block tail publishes the call's sequence number to a pinned host word after its last store; spin on
+  // it (a stream synchronisation costs a marker packet and a signal wake-up on top of the kernels).  Anything unexpected, or a
+  // multi-block tail: synchronise the stream.
+  bool done = false;
+  if (n <= tail_rows_per_block(tail_args(e, e->p_z2, e->Pa, n, 0, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr))) {
+    const int want = ++e->predict_calls;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; !done; ++spins) {
+      done = __atomic_load_n(e->h_done, __ATOMIC_ACQUIRE) == want;
+      if (!done && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (!done) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (__atomic_load_n(e->h_done, __ATOMIC_ACQUIRE) != want) return e->fail(SACTD3_ESTATE, "predict: the acting kernels did not report completion");
+      done = true;
+    }
   }
-  const int mode = td3 ? (explore ? 2 : 0) : (explore ? 0 : 1);
-  ActorTail t = tail_args(e, e->p_z2, e->Pa, n, mode, 0, SACTD3_SITE_PREDICT, 48u, e->h_act, e->a4, 0, nullptr);
-  t.eps_ready = eps_ready;
-  // the tail reads predict_ctr (its noise stream) and may only advance it itself when it is a single block: with more
-  // rows than one block holds, a late block could read the counter after block 0 has bumped it
-  const bool one_block = n <= tail_rows_per_block(t);
-  if (explore && one_block) t.tick = &e->ctl->predict_ctr;
-  RCCHK(launch_tail(e, e->stream, t));
-  if (explore && !one_block) {
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->predict_ctr, (int*)nullptr);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!done) HIPCHK(hipStreamSynchronize(e->stream));
   for (int i = 0; i < n; ++i) memcpy(actions + (size_t)i * e->a, e->h_act + (size_t)i * e->a4, sizeof(float) * e->a);
   return 0;
 }

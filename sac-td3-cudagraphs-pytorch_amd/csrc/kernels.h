@@ -65,7 +65,7 @@ struct DevCtl {
   int rb_len, rb_cursor;
   int inject_idx;
   int inject_eps[8];
-  int pad_;
+  int predict_seq;    // completed sactd3_predict calls (the acting tail publishes it to a pinned host word, see ActorTail::done_flag)
   float metrics[8];
   float adam_q[2], adam_a[2];   // (lr / (1 - b1^t), sqrt(1 - b2^t)) of the critics' / actor's current step
   double pw_q[2], pw_a[2], pw_l[2];   // running b1^t, b2^t of the three optimisers (no pow() on the critical path)
@@ -1547,7 +1547,14 @@ struct ActorTail {
   // agents/agent.py:297-299) sharing this kernel with the next actor update's sample: only its log-prob is kept
   int dual; int site_buf2; unsigned site_code2; float* eps2; float* logp2;
   int eps_ready;                         // the eps buffers were filled by the preceding trunk launch's noise blocks: load, draw nothing
+  // acting path, single-block launches only: after its last store the block bumps *seq and publishes the new value to a pinned
+  // host word -- the host spins on that word instead of paying a stream synchronisation (marker packet + signal wake-up)
+  int* seq; int* done_flag;
 };
+__device__ __forceinline__ void tail_publish(const ActorTail& p, int seq_v) {      // thread 0, after a system-scope fence by all
+  *p.seq = seq_v + 1;
+  __hip_atomic_store(p.done_flag, seq_v + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Memory discipline of this kernel (and of every kernel here): ALL global loads of the common case go out first, behind
 // uniform branches only and with clamped addresses + selects instead of per-lane conditions; they are made to land
@@ -1566,8 +1573,9 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   // ---- loads: counter, stream state, my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3),
   // the operands of this thread's first output element (j = sub), its injected draws, the observation slice to copy
   const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
-  int tick_v = 0;
+  int tick_v = 0, seq_v = 0;
   if (ticker) tick_v = *p.tick;
+  if (p.done_flag && t == 0) seq_v = *p.seq;
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
   // (eps_ready: the buffers already hold this launch's draws -- treated like injected ones)
   const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
@@ -1758,6 +1766,11 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
   if (ticker) *p.tick = tick_v + 1;
+  if (p.done_flag) {                             // (uniform)
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) tail_publish(p, seq_v);
+  }
   STAMP(5);
 }
 
@@ -1775,8 +1788,9 @@ __device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block)
   const int nh = p.L.nh;                         // <= 8, and a <= 8
   const float* Wh = p.P + p.L.Wh;
   const bool ticker = p.tick && block == 0 && t == 0;
-  int tick_v = 0;
+  int tick_v = 0, seq_v = 0;
   if (ticker) tick_v = *p.tick;
+  if (p.done_flag && t == 0) seq_v = *p.seq;
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
   const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
   const unsigned long long seed = p.ctl->seed;
@@ -1895,6 +1909,11 @@ __device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block)
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
   if (ticker) *p.tick = tick_v + 1;
+  if (p.done_flag) {                             // (uniform; RPB == 4: the block is one wave)
+    __threadfence_system();
+    if (RPB > 4) __syncthreads();
+    if (t == 0) tail_publish(p, seq_v);
+  }
 }
 template <int RPB>
 __global__ __launch_bounds__(16 * RPB) void k_actor_tail_s(ActorTail p) { actor_tail_s_body<RPB>(p, blockIdx.x); }

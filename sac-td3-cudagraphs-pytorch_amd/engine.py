@@ -105,6 +105,13 @@ class Engine:
             msg = self.lib.sactd3_last_error(None)
             self._h = C.c_void_p()
             raise EngineError(f"sactd3_create failed ({rc}): {msg.decode() if msg else '?'}")
+        # host-side staging for the per-env-step calls (rb_extend of num_envs rows, predict): numpy -> ctypes pointer conversion
+        # is ~1-2 us per array; these arrays' pointers are made once
+        n0, o, a = max(int(cfg.max_envs), 1), cfg.ob_dim, cfg.ac_dim
+        self._st_n = n0
+        self._st = [np.zeros((n0, o), np.float32), np.zeros((n0, a), np.float32), np.zeros(n0, np.float32),
+                    np.zeros((n0, o), np.float32), np.zeros(n0, np.uint8), np.zeros((n0, o), np.float32), np.zeros((n0, a), np.float32)]
+        self._st_p = [x.ctypes.data_as(C.POINTER(C.c_uint8) if x.dtype == np.uint8 else _F) for x in self._st]
 
     # -- plumbing
     def _ck(self, rc):
@@ -163,6 +170,17 @@ class Engine:
         return obs, act, rew, nobs, done, n
 
     def rb_extend(self, obs, act, rew, nobs, done) -> None:
+        obs = np.asarray(obs)
+        n = obs.size // self.cfg.ob_dim
+        if 0 < n <= self._st_n and obs.size == n * self.cfg.ob_dim:      # an env step's rows: through the pre-bound staging arrays
+            st, p = self._st, self._st_p
+            st[0][:n] = obs.reshape(n, -1)
+            st[1][:n] = np.asarray(act).reshape(n, -1)
+            st[2][:n] = np.asarray(rew).reshape(n)
+            st[3][:n] = np.asarray(nobs).reshape(n, -1)
+            st[4][:n] = np.asarray(done).reshape(n) != 0
+            self._ck(self.lib.sactd3_rb_extend(self._h, p[0], p[1], p[2], p[3], p[4], n))
+            return
         obs, act, rew, nobs, done, n = self._rows(obs, act, rew, nobs, done)
         self._ck(self.lib.sactd3_rb_extend(self._h, _fp(obs), _fp(act), _fp(rew), _fp(nobs),
                                            done.ctypes.data_as(C.POINTER(C.c_uint8)), n))
@@ -264,6 +282,12 @@ class Engine:
         return i
 
     def predict(self, obs, explore: bool) -> np.ndarray:
+        obs = np.asarray(obs)
+        n = obs.size // self.cfg.ob_dim
+        if 0 < n <= self._st_n and obs.size == n * self.cfg.ob_dim:
+            self._st[5][:n] = obs.reshape(n, -1)
+            self._ck(self.lib.sactd3_predict(self._h, self._st_p[5], n, 1 if explore else 0, self._st_p[6]))
+            return self._st[6][:n].copy()
         obs = _f32(obs).reshape(-1, self.cfg.ob_dim)
         out = np.empty((obs.shape[0], self.cfg.ac_dim), np.float32)
         self._ck(self.lib.sactd3_predict(self._h, _fp(obs), obs.shape[0], int(bool(explore)), _fp(out)))
