@@ -124,7 +124,7 @@ struct sactd3_engine {
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   std::vector<hipGraphExec_t> predict_graphs;   // [explore][n]: the two launches of sactd3_predict, captured per row count
   // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
-  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0, tune_nn16 = 0;
+  int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0, tune_nn16 = 0, tune_xr = -1;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
   // node_log set the launch's name and algorithmic FLOPs / bytes are recorded.
@@ -239,6 +239,19 @@ static void launch_nt_f1(hipStream_t s, int ks, int nt, dim3 grid, const NtArgs&
   else if (c1 == 2) launch_nt_ks<PRO, true, 2>(s, ks, grid, g);
   else launch_nt_ks<PRO, true, 4>(s, ks, grid, g);
 }
+// XCD row groups for xcd_tile (kernels.h) of an R x C tile grid whose row operand is A bytes and column operand W bytes: the
+// split xr x xc = 8 with the least total fetch xc A + xr W among those that divide the grid; 0 = keep row-major numbering.
+static int pick_xr(const sactd3_engine* e, int R, int C, double A, double W) {
+  if (e->tune_xr >= 0) return (e->tune_xr == 0 || (R % e->tune_xr == 0 && C % (8 / e->tune_xr) == 0)) ? e->tune_xr : 0;
+  int best = 0; double cost = 1e300;
+  for (int xr = 1; xr <= 8; xr *= 2) {
+    const int xc = 8 / xr;
+    if (R % xr || C % xc) continue;
+    const double c = xc * A + xr * W;
+    if (c < cost) { cost = c; best = xr; }
+  }
+  return best;
+}
 // pro == 0: the generic-K form (unfused first layer).  Otherwise K == 256 and the block shape (16 / 32 / 64 rows x 16
 // columns) is chosen so that the launch has about one block per CU.
 static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro, bool fuse1, const NtArgs& g, int nets, int force_ks = 0) {
@@ -265,6 +278,9 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     if (e->tune_nt == 1 || force_ks) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
+    // unfused launches read whole input rows: place the tiles so that an XCD pulls few rows and few weight columns (the fused
+    // form's input rows are a few dozen bytes: it keeps one weight column tile per XCD, the row-major numbering)
+    gg.xr = fuse1 ? 0 : pick_xr(e, (g.M + rb - 1) / rb, tiles_n / nt, 4.0 * g.M * g.K, 4.0 * g.N * g.K);
     const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0) + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
@@ -296,8 +312,10 @@ static int launch_nn(sactd3_engine* e, hipStream_t s, const char* name, const Nn
     return 0;
   }
   const dim3 grid((unsigned)(((g.M + 15) / 16) * ((g.Kout + 15) / 16)), 1, (unsigned)nets);
+  NnArgs gg = g;
+  gg.xr = pick_xr(e, (g.M + 15) / 16, (g.Kout + 15) / 16, 4.0 * g.M * HID, 4.0 * HID * g.Kout);
   LAUNCH(name, 2.0 * nets * (double)g.M * HID * g.Kout, 4.0 * nets * ((double)g.M * HID + (double)HID * g.Kout + (double)g.M * g.Kout),
-         k_nn, grid, dim3(256), g);
+         k_nn, grid, dim3(256), gg);
   return 0;
 }
 // block tile / chunk rows of the large-batch weight-gradient GEMM (must agree with the k_tn64 instance launched)
@@ -374,6 +392,8 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   int kt = (count(1) * nets > 2 * e->num_cus && g.M < BIG_BATCH) ? 2 : 1;   // (measured: no gain with a thousand rows per tile)
   if (e->tune_tn_kt) kt = e->tune_tn_kt;
   const int tiles = count(kt);
+  for (int i = 0; i < g.nprob; ++i)      // n tiles need dY columns, k tiles X columns (both M rows long)
+    g.pr[i].xr = pick_xr(e, (g.pr[i].N + 15) / 16, ((g.pr[i].ldw + 15) / 16 + kt - 1) / kt, 4.0 * g.M * g.pr[i].N, 4.0 * g.M * g.pr[i].ldw);
   // dW = dY^T X of every problem; operands dY, X once each; the weight block's gradient written, and with the fused
   // optimiser step p, m, v read and written (+ the Polyak target): 4 (g) + 24 (Adam) + 8 (Polyak) bytes per parameter
   double fl = 0.0, by = 0.0;
@@ -963,6 +983,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
   if (const char* f = getenv("SACTD3_NN16")) e->tune_nn16 = atoi(f);
+  if (const char* f = getenv("SACTD3_XR")) e->tune_xr = atoi(f);      // XCD tile placement: -1 (default) = least-fetch split per launch, 0 = row-major
   if (const char* f = getenv("SACTD3_ROWS4")) e->tune_rows4 = atoi(f);
   else e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;   // 4-row (single-wave) k_critic_tail / k_ln_bwd below B = 1024: -1.0 us per Hopper iteration, +-0 at Humanoid
   e->tune_tn64_min = e->num_cus / 2;

@@ -81,6 +81,21 @@ struct NetLayout {   // float offsets inside one net's parameter block (all mult
 // exact n / d for n * d < 2^32 with magic = ceil(2^32 / d) (host-computed); magic == 0: plain division
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned magic) { return magic ? __umulhi(n, magic) : n / d; }
 // one thread: advance an optimiser's step count and publish the step's Adam scalars (torch.optim.Adam bias corrections)
+// Block -> tile placement that minimises what each XCD has to pull from memory (tools/xcd_affinity.hip: data another XCD wrote in
+// the previous kernel comes back at ~2.5 TB/s for the whole chip, ~8 GB/s per CU, where the local L2 delivers it 2-3x faster; the
+// rocprofv3 FETCH_SIZE of these launches was 3-7x their operand bytes because every XCD pulled whole operands).  Workgroups are
+// dealt round-robin over the 8 XCDs by linear id, so the blocks b = x (mod 8) share an L2: they get a compact (R / xr) x (C / xc)
+// sub-grid of the R x C tile grid (xr xc = 8).  A GEMM whose row operand is A bytes and column operand W bytes then fetches
+// xc A + xr W in total instead of 8 A + W.  Needs R % xr == 0 and C % xc == 0 (the host checks; xr = 0: row-major numbering).
+__device__ __forceinline__ void xcd_tile(int b, int R, int C, int xr, int& tr, int& tc) {
+  if (xr <= 0) { tr = b / C; tc = b - tr * C; return; }
+  const int xc = 8 / xr, x = b & 7, j = b >> 3;
+  const int cl = C / xc, rl = R / xr;
+  const int gr = x / xc, gc = x - gr * xc;
+  const int jr = j / cl;
+  tr = gr * rl + jr; tc = gc * cl + (j - jr * cl);
+}
+
 __device__ __forceinline__ void adam_tick(int* t, double* pw, float* out, float lr, float b1, float b2) {
   const int tv = *t;
   double q0 = 0.0, q1 = 0.0;
@@ -460,6 +475,7 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int ring_rows; int nt_blocks; int gblocks; GatherArgs ga;
   // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
   int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
+  int xr;                                // XCD row-block groups of the tile placement (xcd_tile; unfused launches), 0 = row-major numbering
   // One more block (after the gather blocks, net 0 only) can carry the temperature step of the PREVIOUS actor update
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
@@ -517,7 +533,8 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const NtGrp G = p.g[grp];
   const float* Pn = G.P + ni * p.p_ns;
   const int tiles_n = (p.N + 16 * NT - 1) / (16 * NT);
-  const int tmb = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  int tmb, tn;
+  xcd_tile(blockIdx.x, (p.M + RB - 1) / RB, tiles_n, FUSE1 ? 0 : p.xr, tmb, tn);
   const int m0 = tmb * RB + 16 * mt, n0 = tn * 16 * NT;          // this wave's rows / the block's columns
   const int mrow = min(m0 + r, p.M - 1);
   const int kb = (ks * CW) * 16 + 4 * kq;                    // first k of this lane's fragments
@@ -891,6 +908,7 @@ struct NnArgs {              // dX[M,Kout] = dY[M,256] * W[256, k_off : k_off+Ko
   const float* Wt; int ldw; long p_ns; int k_off;
   float* dX; int ldx; long dx_ns;
   int M, Kout;
+  int xr;                                   // k_nn: XCD row groups of the tile placement (xcd_tile), 0 = row-major numbering
 };
 
 __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
@@ -898,7 +916,8 @@ __global__ __launch_bounds__(256) void k_nn(NnArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   const int tiles_k = (p.Kout + 15) >> 4;
-  const int tm = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  int tm, tk;
+  xcd_tile(blockIdx.x, (p.M + 15) >> 4, tiles_k, p.xr, tm, tk);
   const int m0 = tm * 16, k0 = tk * 16;
   const int mrow = min(m0 + r, p.M - 1);
   const int nb = 64 * wave + 4 * kq;
@@ -1127,6 +1146,7 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   int nfin; int fin_slot[3]; int fin_off[3]; int fin_nblk[3];   // vectors from row-kernel partials: part[net][blk][slot][n] summed over blk < fin_nblk
   int fin_s_off; int fin_s_nblk;         // scalar from part_s[net][blk][0] summed over blk (critic head bias), -1: none
   int tile0;                             // first blockIdx.x of this problem
+  int xr;                                // XCD row (n-tile) groups of the tile placement (xcd_tile), 0 = row-major numbering
 };
 struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
   TnProb pr[3]; int nprob; int M;
@@ -1187,7 +1207,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   const TnProb& q = p.pr[pi];    // stays in the kernarg segment (a private copy indexed at run time would be scratch memory)
   const int local = blockIdx.x - q.tile0;
   const int tiles_k = (((q.ldw + 15) >> 4) + KT - 1) / KT;
-  const int tn = local / tiles_k, tk = local % tiles_k;
+  int tn, tk;
+  xcd_tile(local, (q.N + 15) >> 4, tiles_k, q.xr, tn, tk);
   const int n0 = tn * 16, k0 = tk * 16 * KT;
   const long nbase = net * p.g_ns;
   // the epilogue's elements: wave kt < KT, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + 16 kt + j
