@@ -168,7 +168,10 @@ int sactd3_step(sactd3_engine* e, int do_actor);
  * critic-only: one period of the schedule of :345-349 -- as ONE graph launch.  Equal to that many sactd3_step calls, bit for
  * bit.  Needs TD3 or crit_targ_update_freq == 1 (else SACTD3_ESTATE: issue the iterations with sactd3_step). */
 int sactd3_step_period(sactd3_engine* e);
-/* Agent.predict (agents/agent.py:172-181): obs [n, ob_dim] host -> actions [n, ac_dim] host. [sync] */
+/* Agent.predict (agents/agent.py:172-181): obs [n, ob_dim] host -> actions [n, ac_dim] host.  Stream-ordered behind whatever
+ * update was issued before it (it acts with the updated parameters, as the reference does) and returns when ITS kernels have
+ * finished: [sync] in that sense -- with at most 4 rows (16 for wide heads) the wait is a spin on a pinned host word the last
+ * kernel publishes, otherwise a stream synchronisation. */
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions);
 
 int sactd3_read_metrics(sactd3_engine* e, float out[SACTD3_NUM_METRICS]);  /* [sync] */
