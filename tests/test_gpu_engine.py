@@ -518,6 +518,41 @@ def test_predict(algo, env):
         eng.predict(torch.zeros(9, o), explore=False)
 
 
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_predict_returns_only_finished_actions(use_graphs):
+    """sactd3_predict waits for its kernels through a pinned host word the acting tail publishes after its last store (no
+    stream synchronisation for single-block tails).  Alternate two observation sets, with updates and replay writes keeping
+    the stream busy in between: every call must return ITS observations' actions -- a premature return would hand back the
+    previous call's (the staging buffer still holds them).  agents/agent.py:172-181."""
+    o, a, bound = DIMS["hopper"]
+    hps = Hps.sac(batch_size=64)
+    torch.manual_seed(0)
+    ref = RefAgent(o, a, [-bound] * a, [bound] * a, hps)
+    eng = P.Engine(P.Config.from_hps(hps, o, a, rb_capacity=4096, seed=3, use_graphs=use_graphs), [-bound] * a, [bound] * a)
+    push_params(eng, ref)
+    eng.rb_fill_synthetic(1000)
+    g = torch.Generator().manual_seed(5)
+    obs = [torch.randn(4, o, generator=g).numpy(), torch.randn(4, o, generator=g).numpy(), torch.randn(1, o, generator=g).numpy()]
+    want = [eng.predict(x, False).copy() for x in obs]
+    eng.sync()
+    assert not np.allclose(want[0], want[1])
+    rows = [np.zeros((4, o), np.float32), np.zeros((4, a), np.float32), np.zeros(4, np.float32), np.zeros((4, o), np.float32), np.zeros(4, bool)]
+    for i in range(6000):
+        k = i % 3
+        got = eng.predict(obs[k], False)
+        assert np.array_equal(got, want[k]), (i, k)
+    # with the learner running: the parameters move, so compare the two calls of a pair issued back to back on the same observations
+    for i in range(600):
+        eng.rb_extend(*rows)
+        eng.step(i % 3 == 0)
+        x = eng.predict(obs[i % 2], False)
+        y = eng.predict(obs[i % 2], False)
+        assert np.array_equal(x, y) and np.isfinite(x).all(), i
+        z = eng.predict(obs[1 - i % 2], False)
+        assert not np.array_equal(x, z), i
+    eng.close()
+
+
 def test_predict_many_envs_is_reproducible():
     """predict for more rows than one 16-row block (a large vector env): exploitation matches the oracle and the native
     exploration stream is a function of (seed, call number, row) only -- two engines with the same seed agree call by
