@@ -1,7 +1,7 @@
 """The callers on either side of the update path, mirrored from the reference's orchestrator.py so that the engine can
 be driven end to end without tensordict / torchrl / gymnasium being importable:
 
-  segment()     rollout generator                      orchestrator.py:42-118   
+  Rollout / segment()   the acting side + its generator  orchestrator.py:42-118   
   train()       the training loop's control flow       orchestrator.py:317-352 (+ counters :326,342,349)
   episode()     evaluation-episode generator           orchestrator.py:121-246 (lengths / returns, trajectories with need_lists; no pixels)
   evaluate()    offline evaluation of a checkpoint     orchestrator.py:415-481 (trajectory files as .npz)
@@ -25,44 +25,62 @@ from typing import Any, Callable, Dict, Generator, Optional, TextIO
 import numpy as np
 
 
+class Rollout:
+    """The acting side of one learner: the current observations of the vector env, the action in force and the write path
+    into the replay ring.  Two half-steps, because the reference chooses the next action BEFORE it hands control to the learner
+    and steps the env only afterwards (orchestrator.py:62-78): `choose()` then `advance()`.
+
+    Reference behaviour kept (orchestrator.py:42-118): one seeded reset, never again (:53); uniformly random actions while
+    `agent.timesteps_so_far < learning_starts` (:64-65), the policy's exploring action afterwards; an action stays in force for
+    `action_repeat` steps (:62); a truncated env stores its true final observation as the transition's next observation while
+    the rollout continues from the auto-reset one, terminated envs keep the auto-reset one (:86-89); the stored `dones` ARE the
+    terminations (:107-108); every stored field is float32 / bool with `[n, 1]` rewards and flags (:83,91-93,104-105)."""
+
+    def __init__(self, env, agent, seed: int, learning_starts: int, action_repeat: int):
+        assert agent.rb is not None
+        self.env, self.agent = env, agent
+        self.learning_starts, self.action_repeat = learning_starts, action_repeat
+        first, _ = env.reset(seed=seed)
+        self.obs = np.asarray(first, np.float32)
+        self.actions = None
+        self.steps = 0
+
+    def choose(self) -> None:
+        if self.steps % self.action_repeat:
+            return                                                   # the action in force is repeated
+        if self.agent.timesteps_so_far < self.learning_starts:
+            self.actions = self.env.action_space.sample()
+        else:
+            self.actions = self.agent.predict({"observations": self.obs}, explore=True)
+
+    def advance(self) -> None:
+        arrived, rewards, terminations, truncations, infos = self.env.step(self.actions)
+        arrived = np.asarray(arrived, np.float32)
+        stored_next = arrived
+        cut = np.flatnonzero(np.asarray(truncations))
+        if cut.size:                                                 # time-limit cuts: the episode's own last observation is stored
+            stored_next = arrived.copy()
+            for k in cut:
+                stored_next[k] = np.asarray(infos["final_observation"][k], np.float32)
+        ended = np.asarray(terminations, bool).reshape(-1, 1)
+        self.agent.rb.extend({"observations": self.obs, "next_observations": stored_next,
+                              "actions": np.asarray(self.actions, np.float32),
+                              "rewards": np.asarray(rewards, np.float32).reshape(-1, 1),
+                              "terminations": ended, "dones": ended})
+        self.obs = arrived
+        self.steps += 1
+
+
 def segment(env, agent, seed: int, segment_len: int, learning_starts: int, action_repeat: int) -> Generator[None, None, None]:
-    """orchestrator.py:42-118, same order of operations and the same quirks:
-    the env is seeded once (:53); random actions until `learning_starts` (:64-65); the action is refreshed every
-    `action_repeat` steps (:62); the generator yields BEFORE stepping once `segment_len` steps were taken (:77-78);
-    on truncation the stored next observation is the episode's true final observation (:86-89) while terminations keep
-    the auto-reset observation; `dones` is the terminations array (:107-108); everything is float32 (:83,91-93,104-105)."""
-    assert agent.rb is not None
-    obs, _ = env.reset(seed=seed)
-    obs = np.asarray(obs, np.float32)
-    actions = None
-    t = 0
-    r = 0
+    """orchestrator.py:42-118 as a generator over `Rollout`: control goes back to the caller every `segment_len` env steps, AFTER
+    the next action has been chosen and BEFORE the env is stepped with it (:62-78) -- so the action that opens a segment was
+    computed with the parameters of the previous one."""
+    ro = Rollout(env, agent, seed, learning_starts, action_repeat)
     while True:
-        if r % action_repeat == 0:
-            if agent.timesteps_so_far < learning_starts:
-                actions = env.action_space.sample()
-            else:
-                actions = agent.predict({"observations": obs}, explore=True)
-        if t > 0 and t % segment_len == 0:
+        ro.choose()
+        if ro.steps and ro.steps % segment_len == 0:
             yield
-        next_obs, rewards, terminations, truncations, infos = env.step(actions)
-        next_obs = np.asarray(next_obs, np.float32)
-        real_next_obs = next_obs.copy()
-        for idx, trunc in enumerate(np.array(truncations)):
-            if trunc:
-                real_next_obs[idx] = np.asarray(infos["final_observation"][idx], np.float32)
-        terminations = np.asarray(terminations, bool).reshape(-1, 1)
-        agent.rb.extend({
-            "observations": obs,
-            "next_observations": real_next_obs,
-            "actions": np.asarray(actions, np.float32),
-            "rewards": np.asarray(rewards, np.float32).reshape(-1, 1),
-            "terminations": terminations,
-            "dones": terminations,
-        })
-        obs = next_obs
-        t += 1
-        r += 1
+        ro.advance()
 
 
 def train(cfg: Any, env, agent, *, fused: bool = True, on_eval: Optional[Callable[[Any, int], None]] = None,
