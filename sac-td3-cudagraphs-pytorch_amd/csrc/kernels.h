@@ -1596,10 +1596,12 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
   const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
   int tick_v = 0, seq_v = 0;
   if (ticker) tick_v = *p.tick;
-  if (p.done_flag && t == 0) seq_v = *p.seq;
+  if (p.done_flag && t == 0) seq_v = *p.seq;     // (per-lane like the ticker's: a uniform read would be waited for on the spot)
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
   // (eps_ready: the buffers already hold this launch's draws -- treated like injected ones)
-  const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
+  // (the injection flags are fetched unconditionally and combined only where they are used: inside a `need_eps ? load | x : 0`
+  //  the compiler waits for the load on the spot, one round trip ahead of everything below)
+  const int inj1_raw = p.ctl->inject_eps[p.site_buf], inj2_raw = p.ctl->inject_eps[p.dual ? p.site_buf2 : p.site_buf];
   const unsigned long long seed = p.ctl->seed;
   const int ctr = *p.ctr;
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
@@ -1679,6 +1681,7 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
 #pragma unroll
   for (int i = 0; i < OBC; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
   PIN(obt);
+  const int inj1 = (inj1_raw | p.eps_ready) & -(int)need_eps, inj2 = (inj2_raw | p.eps_ready) & -(int)(p.dual != 0);   // (branch-free: see above)
   const float e_eps = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
   const float e_eps2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
   const bool has2 = two && sub + 16 < p.a;
@@ -1811,9 +1814,11 @@ __device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block)
   const bool ticker = p.tick && block == 0 && t == 0;
   int tick_v = 0, seq_v = 0;
   if (ticker) tick_v = *p.tick;
-  if (p.done_flag && t == 0) seq_v = *p.seq;
+  if (p.done_flag && t == 0) seq_v = *p.seq;     // (per-lane like the ticker's: a uniform read would be waited for on the spot)
   const bool need_eps = p.sac ? (p.mode == 0) : (p.mode != 0);
-  const int inj1 = need_eps ? (p.ctl->inject_eps[p.site_buf] | p.eps_ready) : 0, inj2 = p.dual ? (p.ctl->inject_eps[p.site_buf2] | p.eps_ready) : 0;
+  // (the injection flags are fetched unconditionally and combined only where they are used: inside a `need_eps ? load | x : 0`
+  //  the compiler waits for the load on the spot, one round trip ahead of everything below)
+  const int inj1_raw = p.ctl->inject_eps[p.site_buf], inj2_raw = p.ctl->inject_eps[p.dual ? p.site_buf2 : p.site_buf];
   const unsigned long long seed = p.ctl->seed;
   const int ctr = *p.ctr;
   const Row16 z = row_ld(p.z2 + (long)bc * HID, sub);
@@ -1860,6 +1865,7 @@ __device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block)
 #pragma unroll
   for (int i = 0; i < 2; ++i) { PIN(ob4[i].x); PIN(ob4[i].y); PIN(ob4[i].z); PIN(ob4[i].w); }
   PIN(obt);
+  const int inj1 = (inj1_raw | p.eps_ready) & -(int)need_eps, inj2 = (inj2_raw | p.eps_ready) & -(int)(p.dual != 0);   // (branch-free: see above)
   const float e = (need_eps && sub < p.a) ? (inj1 ? e_in1 : e_nat1) : 0.f;
   const float e2 = (p.dual && sub < p.a) ? (inj2 ? e_in2 : e_nat2) : 0.f;
   if (valid) {
