@@ -11,16 +11,21 @@
 //                     the A fragments in registers; optionally the FIRST layer (x W1^T + b1) is computed in the same kernel
 //                     straight into those fragments (narrow inputs); W tiles parked in LDS, block shape picked per launch
 //   k_nt64 / k_ln_fwd large-batch form of the hidden layers: 64 x 64 LDS-tiled GEMM -> LayerNorm row kernel -> tiled GEMM
-//   k_nn              dX = dY W                     (16 x 16 tile per block, reduction split over the 4 waves)
-//   k_tn              dW = dY^T X for every weight of an update in one launch (+ bias gradient, LayerNorm-affine / head
-//                     gradients from row partials) with the Adam step, Polyak update and loss finalisation in the epilogue
-//   k_actor_tail      LN+ReLU -> head (MFMA, K split over the 4 waves) -> tanh-Gaussian sample + log-prob | TD3 policy
+//   k_nn / k_nn64     dX = dY W                     (16 x 16 tile per block, reduction split over the 4 waves; B >= 1024: LDS-tiled)
+//   k_tn              dW = dY^T X for every weight of an update in one launch (+ bias gradient) with the Adam step and the Polyak
+//                     update in the tile's epilogue; extra blocks of the launch finalise the LayerNorm-affine / head gradients
+//                     from the row kernels' partials, the loss and the noise-counter tick, or lerp TD3's actor target
+//   k_tn64 / k_adam_red   large-batch form: split-M partial tiles into slabs -> fixed-order sum + Adam + Polyak
+//   k_actor_tail(_s, _s2)  LN+ReLU -> head -> tanh-Gaussian sample + log-prob | TD3 policy; _s: narrow heads, a row per 16
+//                     lanes of one wave, no LDS / MFMA; _s2: two such tails in one launch; acting launches publish a completion word
 //   k_critic_tail     twin target Q -> min/mix -> entropy -> Bellman target -> twin MSE -> dQ -> head bwd -> LN bwd
 //   k_actorq_tail     twin Q(s, pi(s)) -> min -> actor loss -> dQ routing -> head bwd -> LN bwd
-//   k_actor_head_bwd  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd (MFMA) -> LN bwd
+//   k_actor_head_bwd(_s)  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd (MFMA; _s: DPP broadcast + FMAs) -> LN bwd
 //   k_ln_bwd          LN+ReLU backward of hidden layer 1 (+ the dQ/da slice product of the actor update)
 //   k_adam / k_polyak / k_alpha_step / k_gradnorm   flat optimiser kernels (stand-alone forms)
-// Row kernels: 256 threads = 16 rows x 16 threads; thread (row, sub) owns columns {4*sub + 64*q + e}.
+// Riding blocks: launches carry independent work as extra blocks (replay gather, N(0,1) draws for the next tail, the previous
+// temperature step, target lerps, gradient finalisation) instead of paying a 2 us graph node for it.  Tile -> XCD placement: xcd_tile.
+// Row kernels: 16 RPB threads = RPB rows x 16 threads (RPB = 16, or 4 = one wave); thread (row, sub) owns columns {4*sub + 64*q + e}.
 // Math follows oracle/manual_grads.py (which is checked against autograd) line by line.
 #pragma once
 #include <hip/hip_runtime.h>
