@@ -62,6 +62,7 @@ def make_engine(w, seed, device_id, rows=None, capacity=None):
         eng.set_params(which, flat)
     if rows is None:
         eng.rb_fill_synthetic(w["rows"], seed=0)  # data seed 0
+    eng.instantiate_graphs()   # capture now: a short --warmup must not leave a graph instantiation inside the timed steps
     eng.sync()
     return eng
 

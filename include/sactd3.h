@@ -168,6 +168,9 @@ int sactd3_step(sactd3_engine* e, int do_actor);
  * critic-only: one period of the schedule of :345-349 -- as ONE graph launch.  Equal to that many sactd3_step calls, bit for
  * bit.  Needs TD3 or crit_targ_update_freq == 1 (else SACTD3_ESTATE: issue the iterations with sactd3_step). */
 int sactd3_step_period(sactd3_engine* e);
+/* Capture and instantiate the hipGraphs of sactd3_step / sactd3_step_period now rather than at their first use (the reference's
+ * CudaGraphModule captures after a warm-up inside the loop, orchestrator.py:313-315); nothing is launched, no state changes. */
+int sactd3_instantiate_graphs(sactd3_engine* e);
 /* Agent.predict (agents/agent.py:172-181): obs [n, ob_dim] host -> actions [n, ac_dim] host.  Stream-ordered behind whatever
  * update was issued before it (it acts with the updated parameters, as the reference does) and returns when ITS kernels have
  * finished: [sync] in that sense -- with at most 4 rows (16 for wide heads) the wait is a spin on a pinned host word the last

@@ -891,12 +891,15 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
 }
 
 template <class F>
-static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue);
+static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue, bool launch = true);
 template <class F>
-static int run_graph(sactd3_engine* e, int which, F&& enqueue) { return run_graph_slot(e, &e->graphs[which], &e->graph_nodes[which], enqueue); }
+static int run_graph(sactd3_engine* e, int which, F&& enqueue, bool launch = true) {
+  return run_graph_slot(e, &e->graphs[which], &e->graph_nodes[which], enqueue, launch);
+}
+// launch == false: capture + instantiate only (sactd3_instantiate_graphs)
 template <class F>
-static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue) {
-  if (!e->cfg.use_graphs) return enqueue(e->stream);
+static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&& enqueue, bool launch) {
+  if (!e->cfg.use_graphs) return launch ? enqueue(e->stream) : 0;
   if (!*slot) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -911,7 +914,7 @@ static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&
     hipGraphDestroy(g);
     if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipGraphInstantiate", he);
   }
-  HIPCHK(hipGraphLaunch(*slot, e->stream));
+  if (launch) HIPCHK(hipGraphLaunch(*slot, e->stream));
   return 0;
 }
 
@@ -1431,6 +1434,29 @@ int sactd3_step_period(sactd3_engine* e) {
     if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
     return 0;
   });
+}
+
+// Capture + instantiate the graphs of sactd3_step (both schedules, with the target update) and sactd3_step_period now instead of
+// at their first use, without launching anything: a caller that times its first iterations (or must not stall in the loop) calls
+// this once after sactd3_create.  No-op with use_graphs == 0.
+int sactd3_instantiate_graphs(sactd3_engine* e) {
+  if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  const bool same_branch = e->cfg.prefer_td3_over_sac || e->cfg.crit_targ_update_freq == 1;
+  for (int act = 0; act < 2; ++act)
+    for (int pol = same_branch ? 1 : 0; pol < 2; ++pol) {      // (the variants without the target update exist only when it is gated)
+      const bool a = act != 0 && e->cfg.actor_update_delay > 0, py = pol != 0;
+      RCCHK(run_graph(e, G_STEP00 + (a ? 2 : 0) + (py ? 1 : 0), [&](hipStream_t s) { return enqueue_step(e, s, a, py); }, false));
+    }
+  if (same_branch && e->cfg.actor_update_delay > 0) {
+    const int n = e->cfg.actor_update_delay + 1;
+    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) {
+      for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0, true, i + 1 < n));
+      if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
+      return 0;
+    }, false));
+  }
+  return 0;
 }
 
 int sactd3_predict(sactd3_engine* e, const float* obs, int n, int explore, float* actions) {

@@ -266,6 +266,10 @@ class Engine:
         """actor_update_delay + 1 iterations (actor updates in the first) as one graph launch."""
         self._ck(self.lib.sactd3_step_period(self._h))
 
+    def instantiate_graphs(self) -> None:
+        """capture + instantiate the step / period graphs now instead of at their first use (nothing is launched)."""
+        self._ck(self.lib.sactd3_instantiate_graphs(self._h))
+
     def run_iterations(self, i0: int, n: int) -> int:
         """iterations i0 .. i0 + n - 1 of the loop (orchestrator.py:337-352 schedule: actor updates when i % (delay + 1) == 0),
         whole periods as one graph launch each, the rest one by one.  Returns i0 + n."""

@@ -488,6 +488,24 @@ def test_period_graph_equals_single_iterations(algo, env, B):
         assert eng.run_iterations(0, 7) == 7 and eng.get_adam_state(_lib.CRITICS)[2] == 7
 
 
+def test_graphs_can_be_instantiated_ahead_of_the_first_step():
+    """sactd3_instantiate_graphs captures the step / period graphs without launching or changing anything: the node counts are
+    there before any iteration ran, and the iterations that follow are bit-identical to those of an engine that captured lazily."""
+    res = []
+    for ahead in (True, False):
+        ref, eng, (o, a, bound) = make_pair("sac", "hopper", 64, seed=9)
+        eng.rb_extend(*[t.numpy() for t in synth_transitions(500, o, a, bound, seed=2)])
+        if ahead:
+            before = (eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS))
+            eng.instantiate_graphs()
+            assert eng.graph_kernel_count(2) == 7 and eng.graph_kernel_count(3) > 20 and eng.graph_kernel_count(4) > 30
+            assert np.array_equal(before[0], eng.get_params(_lib.ACTOR)) and np.array_equal(before[1], eng.get_params(_lib.CRITICS))
+        eng.run_iterations(0, 7)
+        res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"]))
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+
+
 def test_native_noise_stream_matches_philox_oracle():
     ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256, seed=77)
     obs, act, rew, nobs, done = synth_transitions(256, o, a, bound, seed=1)
