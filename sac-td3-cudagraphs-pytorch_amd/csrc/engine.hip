@@ -467,6 +467,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
     for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
     g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
+    g.tick0b = tk.tick0b; g.adam_out_b = tk.adam_out_b; g.adam_pw_b = tk.adam_pw_b; g.lr_b = tk.lr_b;
     const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64) * nets));
     const double by_w = 4.0 * nets * (double)HID, by_rows = 4.0 * nets * (double)M * HID;
     LAUNCH_DYN("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
@@ -514,6 +515,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   g.ldy = HID; g.y_ns = (long)M * HID; g.M = M; g.N = HID; g.K = K;
   for (int i = 0; i < ngrp; ++i) { g.g[i].in = grp[i].x; g.g[i].P = grp[i].P; g.g[i].Y = grp[i].z1; }
   g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
+  g.tick0b = tk.tick0b; g.adam_out_b = tk.adam_out_b; g.adam_pw_b = tk.adam_pw_b; g.lr_b = tk.lr_b;
   if (M >= BIG_BATCH && M == e->B) {   // large batch, too few nets for 64 x 64 tiles to fill the chip: 32 x 32 LDS-tiled form
     const dim3 grid((unsigned)(((M + 31) / 32) * (HID / 32) * nets));
     LAUNCH("k_nt64<2,2,1>.layer1", 2.0 * nets * (double)M * HID * K, 4.0 * (nets * (double)HID * (K + 1) + ngrp * (double)M * K + nets * (double)M * HID),
@@ -600,9 +602,13 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   const float* Pact = td3 ? e->Ta : e->Pa;
   {
     const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
-    const bool merge_policy = with_policy && in_kernel_gather;      // the FIRST actor update's pi(s) pass rides along (see enqueue_step)
+    // the FIRST actor update's pi(s) pass rides along (see enqueue_step): in the fused-first-layer launches of narrow observations,
+    // and as a second group of the layer-by-layer launches of wide ones at large batch (Humanoid: two nodes fewer per actor iteration)
+    const bool wide_merge = with_policy && fused_sample && !in_kernel_gather && e->o > 64 && B >= BIG_BATCH && !(e->tune_rows4 & 16);
+    const bool merge_policy = with_policy && (in_kernel_gather || wide_merge);
     e->node_role = fused_sample ? (merge_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
-    TrunkGrp g[2] = {{e->Xn, Pact, e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
+    // (layer-by-layer launches materialise z1: the target-action group borrows the target critics' z1 slab, idle until the next launch)
+    TrunkGrp g[2] = {{e->Xn, Pact, wide_merge ? e->t_z1 : e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
                      {e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
     tk.fuse_gather = in_kernel_gather;
@@ -622,7 +628,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       // the policy sample of the first actor update: same actor parameters (the critic update does not touch them), the stream
       // counter one ahead (the critic update's last kernel bumps it before the actor update would have read it)
       if (!td3) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, 1 + owed, B); tk.noise_taken = &eps_ready; }
-      tk.force_ks = 4;
+      if (!wide_merge) tk.force_ks = 4;
       tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
     }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, merge_policy ? 2 : 1, 1, g, tk));
@@ -636,11 +642,12 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       LAUNCH("k_actor_tail_s2<4>", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
              k_actor_tail_s2<4>, dim3(2 * nb), dim3(64), t, t1, nb);
       if (policy_done) *policy_done = true;
-    } else if (merge_policy) {                  // (wide heads: the two tails as two launches of the general kernel)
-      RCCHK(launch_tail(e, s, t));
+    } else if (merge_policy) {                  // (wide heads: the two tails as one launch of the general kernel)
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
       t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;
-      RCCHK(launch_tail(e, s, t1));
+      const int nb = (B + 15) / 16;
+      LAUNCH("k_actor_tail2", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
+             k_actor_tail2, dim3(2 * nb), dim3(256), t, t1, nb);
       if (policy_done) *policy_done = true;
     } else RCCHK(launch_tail(e, s, t));
   }

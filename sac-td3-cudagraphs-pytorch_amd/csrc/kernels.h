@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const int mt = wave / KS, ks = wave % KS;
   if (blockIdx.x == 0 && net == 0) {
     if (t == 0 && (p.tick0 || p.tick1)) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
-    if (FUSE1 && t == 64 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
+    if (t == 64 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
   }
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256) void k_nt_wide(NtArgs p) {
   if (blockIdx.x == 0 && t == 0 && net == 0) {
     if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
+  if (blockIdx.x == 0 && t == 64 && net == 0 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
   const float* Pn = G.P + ni * p.p_ns;
@@ -792,6 +793,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   if (blockIdx.x == 0 && t == 0) {
     if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
+  if (blockIdx.x == 0 && t == 64 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
   // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a contiguous run of tiles (half a net's 16 x 4 tile
   // grid at B = 1024) so that the A-row and W-column tiles its 32 CUs share are fetched into that XCD's L2 once.
   const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
@@ -1586,19 +1588,19 @@ __device__ __forceinline__ void tail_publish(const ActorTail& p, int seq_v) {   
 // uniform branches only and with clamped addresses + selects instead of per-lane conditions; they are made to land
 // (PIN) before the first global store.  A load that follows a store, or one that is first used inside a divergent
 // branch, costs a full drain of the memory queue (s_waitcnt vmcnt(0)) -- a round trip each, and there were ~20 here.
-__global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
+__device__ __forceinline__ void actor_tail_body(const ActorTail& p, int block) {
   __shared__ __attribute__((aligned(16))) float Hs[16 * AS];
   __shared__ float Up[4 * 16 * 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row = t >> 4, sub = t & 15, r = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.x * 16 + row, bc = min(b, p.B - 1);
+  const int b = block * 16 + row, bc = min(b, p.B - 1);
   const bool valid = b < p.B;
   const int nh = p.L.nh, T = (nh + 15) >> 4;     // head column tiles (<= 4)
   const float* Wh = p.P + p.L.Wh;
   STAMP(0);
   // ---- loads: counter, stream state, my row, LN affine, my head-weight fragments (wave w: k chunks 4w .. 4w+3),
   // the operands of this thread's first output element (j = sub), its injected draws, the observation slice to copy
-  const bool ticker = p.tick && blockIdx.x == 0 && t == 0;
+  const bool ticker = p.tick && block == 0 && t == 0;
   int tick_v = 0, seq_v = 0;
   if (ticker) tick_v = *p.tick;
   if (p.done_flag && t == 0) seq_v = *p.seq;     // (per-lane like the ticker's: a uniform read would be waited for on the spot)
@@ -1801,6 +1803,12 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) {
     if (t == 0) tail_publish(p, seq_v);
   }
   STAMP(5);
+}
+__global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) { actor_tail_body(p, blockIdx.x); }
+// two tails in one launch (wide heads; see k_actor_tail_s2)
+__global__ __launch_bounds__(256) void k_actor_tail2(ActorTail a, ActorTail b, int nb_a) {
+  if ((int)blockIdx.x < nb_a) actor_tail_body(a, blockIdx.x);
+  else actor_tail_body(b, blockIdx.x - nb_a);
 }
 
 // Narrow heads (nh <= 8: Hopper's SAC head 2 x 3, HalfCheetah's TD3 head 6 ...).  The general kernel above spends two block
