@@ -282,7 +282,7 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     // form's input rows are a few dozen bytes: it keeps one weight column tile per XCD, the row-major numbering)
     gg.xr = fuse1 ? 0 : pick_xr(e, (g.M + rb - 1) / rb, tiles_n / nt, 4.0 * g.M * g.K, 4.0 * g.N * g.K);
     const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0);
-    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + (fuse1 ? gg.alpha_block : 0) + nzb), 1, (unsigned)nets);
+    const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + gg.alpha_block + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
     if (e->node_log) {
       const int c1 = (g.K1 + 15) / 16;
@@ -457,7 +457,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   }
   const int nets = ngrp * npg;
   const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4;
-  if (tk.alpha && (big_path || K > 64)) {   // only the fused-first-layer launch can carry it: otherwise its own node, first
+  if (tk.alpha && big_path) {   // the k_nt launches (fused, or the layer-2 one below) carry it as an extra block; the tiled form has none: own node, first
     LAUNCH("k_alpha_step", 0.0, 4.0 * M, k_alpha_step, dim3(1), dim3(256), *tk.alpha);
   }
   // MFMA-bound sizes with enough 64 x 64 tiles to fill the chip: tiled GEMM -> LayerNorm row kernel -> tiled GEMM
@@ -523,6 +523,7 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   } else RCCHK(launch_nt(e, s, "layer1", 0, false, g, nets));
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
+  if (tk.alpha) { h.alpha_block = 1; h.al = *tk.alpha; }   // (never together with noise blocks: those read the counter it ticks)
   if (tk.nnoise > 0) {   // (as in the fused form) the following tail's draws as extra blocks of the layer-2 launch
     h.nz_n = tk.nnoise; h.nz_ctl = e->ctl;
     for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
