@@ -586,6 +586,15 @@ static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
   return 0;
 }
 
+// Can the actor trunk that opens an iteration (1 net, or 2 groups when the policy pass is merged in) carry a temperature step as an
+// extra block?  The k_nt launches can (fused first layer, or the layer-2 launch of the layer-by-layer form); the tiled k_nt64 pair
+// of launches with >= 3/4 of the chip in 64 x 64 tiles cannot (see enqueue_trunk).
+static bool opening_trunk_carries_alpha(const sactd3_engine* e) {
+  const int B = e->B;
+  const bool tiled = B >= BIG_BATCH && ((B + 63) / 64) * (HID / 64) * 2 >= (3 * e->num_cus) / 4;
+  return !tiled;
+}
+
 // agents/agent.py:183-242
 // fused_sample: this update opens a fused iteration and owns the replay sampling (orchestrator.py:338); with a narrow
 // observation the gather rides in the first trunk kernel, otherwise enqueue_step has launched k_gather just before.
@@ -619,7 +628,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     // a temperature step deferred from the previous iteration of the same graph (sactd3_step_period) rides in this launch; its
     // tick of the noise counter is owed: this iteration's draws count one ahead and the critics' last kernel ticks by two
     int owed = 0;
-    if (e->alpha_pending && e->alpha_tick_owed && in_kernel_gather) {
+    if (e->alpha_pending && e->alpha_tick_owed && fused_sample && opening_trunk_carries_alpha(e)) {
       tk.alpha = &e->pending_alpha; e->alpha_pending = false; e->alpha_tick_owed = false;
       owed = 1;
       for (int i = 0; i < tk.nnoise; ++i) tk.noise[i].ctr_add += 1;
@@ -889,8 +898,8 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
       const bool last = j + 1 == n;
       float* pt = nullptr;
       if (actor_targ && last) { pt = e->Ta; actor_targ_done = true; }
-      // the last temperature step can wait for the next iteration's first launch when that launch is the fused-first-layer kind
-      const bool defer = last && next_in_same_graph && !td3 && e->o <= 64 && e->B < BIG_BATCH;
+      // the last temperature step can wait for the next iteration's opening trunk launch when that launch can carry it
+      const bool defer = last && next_in_same_graph && !td3 && opening_trunk_carries_alpha(e);
       RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer));
     }
   }
