@@ -517,7 +517,14 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   g.tick0 = tk.tick0; g.tick1 = tk.tick1; g.adam_out = tk.adam_out; g.adam_pw = tk.adam_pw; g.lr = tk.lr; g.b1 = e->cfg.adam_beta1; g.b2 = e->cfg.adam_beta2;
   g.tick0b = tk.tick0b; g.adam_out_b = tk.adam_out_b; g.adam_pw_b = tk.adam_pw_b; g.lr_b = tk.lr_b;
   if (M >= BIG_BATCH && M == e->B) {   // large batch, too few nets for 64 x 64 tiles to fill the chip: 32 x 32 LDS-tiled form
-    const dim3 grid((unsigned)(((M + 31) / 32) * (HID / 32) * nets));
+    unsigned nblk = (unsigned)(((M + 31) / 32) * (HID / 32) * nets);
+    if (tk.fuse_gather) {   // x = the field of the sampled records itself; extra blocks fill the batch slot (as in the fused k_nt form)
+      g.ring_rows = 1; g.ga = gather_args(e, e->ring, -1);
+      for (int i = 0; i < ngrp; ++i) g.g[i].ring_off = grp[i].ring_off;
+      g.gblocks = (int)gather_blocks((long)e->B * e->rec4); g.nt_blocks = (int)nblk;
+      nblk += (unsigned)g.gblocks;
+    }
+    const dim3 grid(nblk);
     LAUNCH("k_nt64<2,2,1>.layer1", 2.0 * nets * (double)M * HID * K, 4.0 * (nets * (double)HID * (K + 1) + ngrp * (double)M * K + nets * (double)M * HID),
            (k_nt64<2, 2, 1>), grid, dim3(256), g);
   } else RCCHK(launch_nt(e, s, "layer1", 0, false, g, nets));
@@ -589,6 +596,13 @@ static int launch_adam(sactd3_engine* e, hipStream_t s, const AdamArgs& a) {
 // Can the actor trunk that opens an iteration (1 net, or 2 groups when the policy pass is merged in) carry a temperature step as an
 // extra block?  The k_nt launches can (fused first layer, or the layer-2 launch of the layer-by-layer form); the tiled k_nt64 pair
 // of launches with >= 3/4 of the chip in 64 x 64 tiles cannot (see enqueue_trunk).
+static bool opening_trunk_carries_alpha(const sactd3_engine* e);
+// Does the actor trunk that opens a fused iteration read its rows from the ring itself, with the gather into the batch slot riding in
+// the same launch?  Narrow observations below the large-batch threshold (fused k_nt), and wide ones at large batch (k_nt64<2,2,1>).
+static bool opening_trunk_gathers(const sactd3_engine* e) {
+  if (e->tune_rows4 & 32) return e->o <= 64 && e->B < BIG_BATCH;
+  return (e->o <= 64 && e->B < BIG_BATCH) || (e->o > 64 && e->B >= BIG_BATCH && opening_trunk_carries_alpha(e));
+}
 static bool opening_trunk_carries_alpha(const sactd3_engine* e) {
   const int B = e->B;
   const bool tiled = B >= BIG_BATCH && ((B + 63) / 64) * (HID / 64) * 2 >= (3 * e->num_cus) / 4;
@@ -611,11 +625,11 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
   {
-    const bool in_kernel_gather = fused_sample && e->o <= 64 && B < BIG_BATCH;
+    const bool in_kernel_gather = fused_sample && opening_trunk_gathers(e);
     // the FIRST actor update's pi(s) pass rides along (see enqueue_step): in the fused-first-layer launches of narrow observations,
     // and as a second group of the layer-by-layer launches of wide ones at large batch (Humanoid: two nodes fewer per actor iteration)
-    const bool wide_merge = with_policy && fused_sample && !in_kernel_gather && e->o > 64 && B >= BIG_BATCH && !(e->tune_rows4 & 16);
-    const bool merge_policy = with_policy && (in_kernel_gather || wide_merge);
+    const bool wide_merge = with_policy && fused_sample && e->o > 64 && B >= BIG_BATCH && !(e->tune_rows4 & 16);
+    const bool merge_policy = with_policy && ((in_kernel_gather && e->o <= 64) || wide_merge);
     e->node_role = fused_sample ? (merge_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
     // (layer-by-layer launches materialise z1: the target-action group borrows the target critics' z1 slab, idle until the next launch)
     TrunkGrp g[2] = {{e->Xn, Pact, wide_merge ? e->t_z1 : e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
@@ -880,7 +894,7 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak, bool next_in_same_graph = false) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   e->node_role = "sample";
-  if (e->o > 64 || e->B >= BIG_BATCH) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
+  if (!opening_trunk_gathers(e)) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
   // Target updates (agents/agent.py:320-331) are folded into the kernels that apply the optimiser steps: the critic targets are

@@ -790,6 +790,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   __shared__ __attribute__((aligned(16))) float Ws[2][TN * LS64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave % WM, wn = wave / WM;
   const int r = lane & 15, kq = lane >> 4;
+  // (256-thread instances) the replay gather into the batch slot as extra blocks behind the tile blocks, as in k_nt: the tile
+  // blocks read their rows straight from the ring (ring_rows below), so nothing in this launch waits for the batch slot
+  const int tile_blocks = p.gblocks ? p.nt_blocks : (int)gridDim.x;
+  if (NTH == 256 && p.gblocks && (int)blockIdx.x >= tile_blocks) { gather_body(p.ga, blockIdx.x - tile_blocks); return; }
   if (blockIdx.x == 0 && t == 0) {
     if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   // grid at B = 1024) so that the A-row and W-column tiles its 32 CUs share are fetched into that XCD's L2 once.
   const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
   int L = blockIdx.x;
-  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }
+  { const int per = tile_blocks >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }
   const int net = L / tiles, idx = L - net * tiles;
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
@@ -811,6 +815,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   const float* ap[RA]; const float* wp[RW];
 #pragma unroll
   for (int u = 0; u < RA; ++u) ap[u] = A + (long)min(m0 + sr0 + SR * u, p.M - 1) * p.ld_in;
+  if (p.ring_rows) {                              // (uniform) row m = the sampled record's field: same draw as gather_body's
+    const int inject = p.ga.ctl->inject_idx, rb_len = p.ga.ctl->rb_len, sctr = p.ga.ctl->sample_ctr;   // one batch of requests
+    const unsigned long long seed = p.ga.ctl->seed;
+#pragma unroll
+    for (int u = 0; u < RA; ++u) {
+      const int m = min(m0 + sr0 + SR * u, p.M - 1);
+      int id = (int)philox_index(seed, (unsigned)sctr, (unsigned)m, (unsigned)max(rb_len, 1));
+      if (inject) id = p.ga.idx[m];
+      ap[u] = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + G.ring_off;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < RW; ++u) wp[u] = Pn + p.oW + (long)min(n0 + sr0 + SR * u, p.N - 1) * p.ldw;
   const int Kr = (p.K + 3) & ~3;
