@@ -818,11 +818,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   if (p.ring_rows) {                              // (uniform) row m = the sampled record's field: same draw as gather_body's
     const int inject = p.ga.ctl->inject_idx, rb_len = p.ga.ctl->rb_len, sctr = p.ga.ctl->sample_ctr;   // one batch of requests
     const unsigned long long seed = p.ga.ctl->seed;
+    int inj_id[RA];                                 // injected indices: requested with the control words, used only in injected mode
+#pragma unroll                                      // (a load behind `if (inject)` would be a second dependent round trip)
+    for (int u = 0; u < RA; ++u) inj_id[u] = p.ga.idx[min(m0 + sr0 + SR * u, p.M - 1)];
+    __builtin_amdgcn_sched_barrier(0);              // all of the above are in flight before the first of them is waited for
 #pragma unroll
     for (int u = 0; u < RA; ++u) {
       const int m = min(m0 + sr0 + SR * u, p.M - 1);
-      int id = (int)philox_index(seed, (unsigned)sctr, (unsigned)m, (unsigned)max(rb_len, 1));
-      if (inject) id = p.ga.idx[m];
+      const int drawn = (int)philox_index(seed, (unsigned)sctr, (unsigned)m, (unsigned)max(rb_len, 1));
+      const int id = inject ? min(max(inj_id[u], 0), max(rb_len, 1) - 1) : drawn;
       ap[u] = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + G.ring_off;
     }
   }
