@@ -472,23 +472,39 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     const double by_w = 4.0 * nets * (double)HID, by_rows = 4.0 * nets * (double)M * HID;
     LAUNCH_DYN("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
                (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, g);
-    LnFwd l{};
-    l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
+    if (e->tune_rows4 & 128) {   // (A/B: the separate LayerNorm row kernel between the two tiled GEMMs)
+      LnFwd l{};
+      l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
+      for (int i = 0; i < ngrp; ++i) {
+        l.P[i] = grp[i].P; l.zin[i] = grp[i].z1;
+        l.h[i] = grp[i].h ? grp[i].h : e->s_h1 + (size_t)i * npg * M * HID;
+        l.xh[i] = grp[i].xh; l.rstd[i] = grp[i].rstd;
+      }
+      {
+        double st = 1.0;   // rows written: h always, xhat where the caller keeps it
+        for (int i = 0; i < ngrp; ++i) st += grp[i].xh ? 1.0 / ngrp : 0.0;
+        LAUNCH("k_ln_fwd", 0.0, by_rows * (1.0 + st), k_ln_fwd, dim3((unsigned)((M + 15) / 16), (unsigned)nets), dim3(256), l);
+      }
+      NtArgs h2{};
+      h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
+      h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
+      for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
+      LAUNCH_DYN("k_nt64<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 1) + 2.0 * by_rows, (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, h2);
+      return 0;
+    }
+    // second layer with the LayerNorm + ReLU of the first as its prologue (k_nt64_ln): no row kernel in between
+    NtArgs h2{};
+    h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.oG = L.g1; h2.oBe = L.be1; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
+    h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID; h2.act_ns = (long)M * HID; h2.ln_pro = e->cfg.layer_norm ? 1 : 0;
     for (int i = 0; i < ngrp; ++i) {
-      l.P[i] = grp[i].P; l.zin[i] = grp[i].z1;
-      l.h[i] = grp[i].h ? grp[i].h : e->s_h1 + (size_t)i * npg * M * HID;
-      l.xh[i] = grp[i].xh; l.rstd[i] = grp[i].rstd;
+      h2.g[i].in = grp[i].z1; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2;
+      h2.g[i].h_out = grp[i].h; h2.g[i].xh_out = grp[i].xh; h2.g[i].rstd_out = grp[i].rstd;
     }
     {
-      double st = 1.0;   // rows written: h always, xhat where the caller keeps it
-      for (int i = 0; i < ngrp; ++i) st += grp[i].xh ? 1.0 / ngrp : 0.0;
-      LAUNCH("k_ln_fwd", 0.0, by_rows * (1.0 + st), k_ln_fwd, dim3((unsigned)((M + 15) / 16), (unsigned)nets), dim3(256), l);
+      double st = 0.0;   // rows written besides the output: h and xhat where the caller keeps them
+      for (int i = 0; i < ngrp; ++i) st += ((grp[i].xh ? 1.0 : 0.0) + (grp[i].h ? 1.0 : 0.0)) / ngrp;
+      LAUNCH_DYN("k_nt64_ln<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 3) + by_rows * (2.0 + st), (k_nt64_ln<4, 2, 2>), grid, dim3(512), e->tune_pad64, h2);
     }
-    NtArgs h2{};
-    h2.npg = npg; h2.oW = L.W2; h2.ldw = HID; h2.oBias = L.b2; h2.p_ns = p_ns; h2.ld_in = HID; h2.in_ns = (long)M * HID;
-    h2.ldy = HID; h2.y_ns = (long)M * HID; h2.M = M; h2.N = HID; h2.K = HID;
-    for (int i = 0; i < ngrp; ++i) { h2.g[i].in = l.h[i]; h2.g[i].P = grp[i].P; h2.g[i].Y = grp[i].z2; }
-    LAUNCH_DYN("k_nt64<4,2,2>.layer2", 2.0 * nets * (double)M * HID * HID, by_w * (HID + 1) + 2.0 * by_rows, (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, h2);
     return 0;
   }
   if (K <= 64) {

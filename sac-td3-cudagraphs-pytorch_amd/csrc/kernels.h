@@ -481,6 +481,7 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
   int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
   int xr;                                // XCD row-block groups of the tile placement (xcd_tile; unfused launches), 0 = row-major numbering
+  int ln_pro;                            // k_nt64_ln: 1 = LayerNorm + ReLU of the input rows, 0 = ReLU only (layer_norm off)
   // One more block (after the gather blocks, net 0 only) can carry the temperature step of the PREVIOUS actor update
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
@@ -901,6 +902,114 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
     }
   }
   STAMP(2);
+}
+
+// Second hidden layer of the large-batch multi-net trunks WITH the first layer's LayerNorm + ReLU as its prologue (the k_ln_fwd row
+// kernel between the two tiled GEMMs, one graph node and 10 MB of traffic, folded in).  K = 256 = one row per 16 threads in exactly
+// k_nt64's staging map (thread (row = t >> 4 + SR u, sub = t & 15) owns columns 4 sub + 64 q -- the Row16 layout), so a block loads
+// its TM rows ONCE, up front, normalises them in registers with the same two DPP row reductions as k_ln_fwd (bit-identical
+// statistics), and parks chunk c of the activated rows from registers while the loop streams only W.  The column-tile-0 block of
+// every row block stores h / xhat / rstd where the backward pass wants them.
+template <int WM, int WN, int TT>
+__global__ __launch_bounds__(64 * WM * WN) void k_nt64_ln(NtArgs p) {       // Y[M,N] = relu(LN(Z))[M,256] W[N,256]^T + bias
+  constexpr int TM = 16 * WM, TN = 16 * TT * WN, NTH = 64 * WM * WN, NC = HID / KC64;
+  constexpr int RA = 16 * TM / NTH, RW = 16 * TN / NTH, SR = NTH / 16;
+  static_assert(RA >= 1 && RW >= 1 && 16 * TM % NTH == 0 && 16 * TN % NTH == 0 && NC == 4, "staging map");
+  __shared__ __attribute__((aligned(16))) float As[2][TM * LS64];
+  __shared__ __attribute__((aligned(16))) float Ws[2][TN * LS64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave % WM, wn = wave / WM;
+  const int r = lane & 15, kq = lane >> 4;
+  const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
+  int L = blockIdx.x;
+  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }      // XCD-contiguous tile runs (see k_nt64)
+  const int net = L / tiles, idx = L - net * tiles;
+  const int grp = net / p.npg, ni = net - grp * p.npg;
+  const NtGrp G = p.g[grp];
+  const float* Pn = G.P + ni * p.p_ns;
+  const float* Z = G.in + ni * p.in_ns;
+  const int bm = idx / tiles_n, bn = idx - bm * tiles_n;
+  const int m0 = bm * TM, n0 = bn * TN;
+  const int sr0 = t >> 4, sub = t & 15, sc = sub * 4;
+  // ---- every load of the prologue + the first W chunk
+  Row16 z[RA];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) z[u] = row_ld(Z + (long)min(m0 + sr0 + SR * u, p.M - 1) * p.ld_in, sub);
+  const Row16 g = row_ld(Pn + (p.ln_pro ? p.oG : 0), sub), be = row_ld(Pn + (p.ln_pro ? p.oBe : 0), sub);   // unconditional: one batch
+  const float* wp[RW];
+#pragma unroll
+  for (int u = 0; u < RW; ++u) wp[u] = Pn + p.oW + (long)min(n0 + sr0 + SR * u, p.N - 1) * p.ldw;
+  float bias[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) bias[tt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 16 * TT * wn + 16 * tt + r, p.N - 1)] : 0.f;
+  float4 rw[RW];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < RW; ++u) rw[u] = ld4(wp[u] + c * KC64 + sc);
+  };
+  fetch(0);
+  // ---- LayerNorm + ReLU of this thread's rows (k_ln_fwd's arithmetic), stores by the column-tile-0 block
+  Row16 h[RA];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) {
+    Row16 xh, y; float rstd;
+    ln_fwd(z[u], g, be, p.ln_pro, xh, y, rstd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[u].v[q] = relu4(y.v[q]);
+    const int row = m0 + sr0 + SR * u;
+    if (bn == 0 && row < p.M) {                    // (block-uniform first half)
+      const long ro = ni * p.act_ns + (long)row * HID;
+      if (G.h_out) row_st(G.h_out + ro, sub, h[u]);
+      if (G.xh_out) row_st(G.xh_out + ro, sub, xh);
+      if (G.rstd_out && sub == 0) G.rstd_out[(long)ni * p.M + row] = rstd;
+    }
+  }
+  auto park = [&](int buf, auto ctag) {
+    constexpr int c = decltype(ctag)::value;
+#pragma unroll
+    for (int u = 0; u < RA; ++u) st4(As[buf] + (sr0 + SR * u) * LS64 + sc, h[u].v[c]);
+#pragma unroll
+    for (int u = 0; u < RW; ++u) st4(Ws[buf] + (sr0 + SR * u) * LS64 + sc, rw[u]);
+  };
+  f32x4 acc[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int buf) {
+    const float* ab = As[buf] + (16 * wm + r) * LS64 + 4 * kq;
+    const float* wb = Ws[buf] + (16 * TT * wn + r) * LS64 + 4 * kq;
+#pragma unroll
+    for (int s2 = 0; s2 < KC64 / 16; ++s2) {
+      const float4 a = ld4(ab + 16 * s2);
+      float4 b[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) b[tt] = ld4(wb + 16 * tt * LS64 + 16 * s2);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[tt].x, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[tt].y, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[tt].z, acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[tt].w, acc[tt], 0, 0, 0);
+    }
+  };
+  // 4 chunks, unrolled by hand (the parked register set is selected at compile time: a run-time index would be scratch memory)
+  park(0, std::integral_constant<int, 0>{});
+  __syncthreads();
+  fetch(1); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0); park(1, std::integral_constant<int, 1>{}); __syncthreads();
+  fetch(2); __builtin_amdgcn_sched_barrier(0); mma(1); __builtin_amdgcn_sched_barrier(0); park(0, std::integral_constant<int, 2>{}); __syncthreads();
+  fetch(3); __builtin_amdgcn_sched_barrier(0); mma(0); __builtin_amdgcn_sched_barrier(0); park(1, std::integral_constant<int, 3>{}); __syncthreads();
+  mma(1);
+  float* y = G.Y + ni * p.y_ns;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int col = n0 + 16 * TT * wn + 16 * tt + r;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 16 * wm + 4 * kq + i;
+      if (row < p.M) y[(long)row * p.ldy + col] = acc[tt][i] + bias[tt];
+    }
+  }
 }
 
 struct LnFwd {               // h = relu(LN(z) * gamma + beta) per row; stores h, xhat, rstd   (nets on blockIdx.y)
