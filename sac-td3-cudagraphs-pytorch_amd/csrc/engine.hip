@@ -552,6 +552,16 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
     if (tk.noise_taken) *tk.noise_taken = true;
   }
+  if (M >= BIG_BATCH && M == e->B && !(e->tune_rows4 & 256)) {   // large batch: the 32 x 32 LDS-tiled form with the LayerNorm prologue
+    h.ln_pro = e->cfg.layer_norm ? 1 : 0;
+    h.nt_blocks = ((M + 31) / 32) * (HID / 32) * nets;
+    const int nzb = (h.nz_n > 0 ? h.nz[0].blocks : 0) + (h.nz_n > 1 ? h.nz[1].blocks : 0);
+    double st = 0.0;
+    for (int i = 0; i < ngrp; ++i) st += ((grp[i].xh ? 1.0 : 0.0) + (grp[i].h ? 1.0 : 0.0)) / ngrp;
+    LAUNCH("k_nt64_ln<2,2,1>.layer2", 2.0 * nets * (double)M * HID * HID, 4.0 * nets * ((double)HID * (HID + 3) + (double)M * HID * (2.0 + st)),
+           (k_nt64_ln<2, 2, 1>), dim3((unsigned)(h.nt_blocks + h.alpha_block + nzb)), dim3(256), h);
+    return 0;
+  }
   return launch_nt(e, s, "layer2", pro, false, h, nets);
 }
 

@@ -919,9 +919,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64_ln(NtArgs p) {       // Y
   __shared__ __attribute__((aligned(16))) float Ws[2][TN * LS64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave % WM, wn = wave / WM;
   const int r = lane & 15, kq = lane >> 4;
+  // (256-thread instance) riding blocks behind the tile blocks, as in k_nt: a pending temperature step, the next tail's N(0,1) draws
+  const int tile_blocks = (p.alpha_block || p.nz_n) ? p.nt_blocks : (int)gridDim.x;
+  if (NTH == 256 && (int)blockIdx.x >= tile_blocks) {
+    const int x = (int)blockIdx.x - tile_blocks;
+    if (x < p.alpha_block) alpha_body(p.al);
+    else if (x < p.alpha_block + p.nz[0].blocks) noise_body(p.nz[0], p.nz_ctl, x - p.alpha_block);
+    else if (p.nz_n > 1) noise_body(p.nz[1], p.nz_ctl, x - p.alpha_block - p.nz[0].blocks);
+    return;
+  }
   const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
   int L = blockIdx.x;
-  { const int per = (int)gridDim.x >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }      // XCD-contiguous tile runs (see k_nt64)
+  { const int per = tile_blocks >> 3; if (L < per * 8) L = (L & 7) * per + (L >> 3); }      // XCD-contiguous tile runs (see k_nt64)
   const int net = L / tiles, idx = L - net * tiles;
   const int grp = net / p.npg, ni = net - grp * p.npg;
   const NtGrp G = p.g[grp];
