@@ -356,7 +356,7 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
   {
     const dim3 grid((unsigned)(tiles * nets * S));
     char inst[96];
-    snprintf(inst, sizeof(inst), "k_tn64.dW(split-M x%d)", S);
+    snprintf(inst, sizeof(inst), "k_tn64<2,2,2,1,64>.dW(split-M x%d)", S);   // (instance = TN64_CFG: the name rocprofv3 reports)
     LAUNCH(inst, fl, by + 4.0 * S * nets * (double)size, TN64_KERNEL, grid, dim3(256), a);
   }
   r.Gp = e->Gp; r.S = S; r.nets = nets; r.g_ns = size; r.G = g.G;
