@@ -478,7 +478,8 @@ def test_fused_step_against_oracle_at_baseline_shapes(algo, env, B, cap):
 
 
 @pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 64), ("td3", "halfcheetah", 64), ("sac", "humanoid", 64),
-                                        ("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024)])
+                                        ("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024),
+                                        ("td3", "humanoid", 1024), ("sac", "hopper", 1024)])     # (wide / narrow observations at large batch)
 def test_fused_step_equals_api_sequence(algo, env, B):
     """sactd3_step (one graph per iteration) == rb_sample + update_qnets + 2x update_actor + update_targ_nets, bit for
     bit, at a small batch and at BASELINE.json's batch sizes (where other kernel instances are chosen)."""
@@ -503,7 +504,8 @@ def test_fused_step_equals_api_sequence(algo, env, B):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024), ("sac", "hopper", 64)])
+@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024), ("sac", "hopper", 64),
+                                        ("td3", "humanoid", 1024)])
 def test_period_graph_equals_single_iterations(algo, env, B):
     """sactd3_step_period (3 iterations of the schedule of orchestrator.py:345-349 in ONE graph: actor updates in the first,
     then two critic-only ones) == three sactd3_step calls, bit for bit; Engine.run_iterations mixes both forms around period
@@ -768,6 +770,8 @@ def test_update_results_are_zero_dim_device_tensors():
     ("td3", "halfcheetah", 256, dict(targ_actor_smoothing=False)),      # agents/agent.py:201-202
     ("td3", "halfcheetah", 256, dict(bcq_style_targ_mix=False)),        # hard min (TD3 paper)
     ("sac", "humanoid", 1024, dict()),                                  # BASELINE config 4 shape (wide first layer, B=1024)
+    ("td3", "humanoid", 1024, dict()),                                  # the same launches with the target actor in the opening group
+    ("sac", "humanoid", 1024, dict(ln=False)),                          # k_nt64_ln's ReLU-only prologue
     ("sac", "hopper", 4096, dict()),                                    # largest batch of the scope (batch <= 4096)
     ("sac", "hopper", 1, dict()),                                       # degenerate batch
 ])
