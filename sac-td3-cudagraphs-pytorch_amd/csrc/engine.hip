@@ -1044,6 +1044,10 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
   if (const char* f = getenv("SACTD3_NN16")) e->tune_nn16 = atoi(f);
   if (const char* f = getenv("SACTD3_XR")) e->tune_xr = atoi(f);      // XCD tile placement: -1 (default) = least-fetch split per launch, 0 = row-major
+  // SACTD3_ROWS4: bit mask of kernel-selection switches, for full-iteration A/B runs (tools/ab_iter.sh).  1 / 2: the 4-row single-wave
+  // k_critic_tail / k_ln_bwd (default ON below B = 1024).  The other bits turn a default OFF: 4 k_actor_head_bwd_s, 16 the policy-pass
+  // merge for wide observations, 32 the in-kernel replay gather of the wide opening trunk, 128 k_nt64_ln in the 4-net trunk (-> k_ln_fwd
+  // + k_nt64), 256 k_nt64_ln<2,2,1> for the 1- / 2-net second layers (-> k_nt).
   if (const char* f = getenv("SACTD3_ROWS4")) e->tune_rows4 = atoi(f);
   else e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;   // 4-row (single-wave) k_critic_tail / k_ln_bwd below B = 1024: -1.0 us per Hopper iteration, +-0 at Humanoid
   e->tune_tn64_min = e->num_cus / 2;
