@@ -551,6 +551,18 @@ def test_graphs_can_be_instantiated_ahead_of_the_first_step():
         res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"]))
     for x, y in zip(*res):
         assert np.array_equal(x, y)
+    # a gated target update (crit_targ_update_freq = 2): both variants of the step graphs are captured, no period graph
+    res = []
+    for ahead in (True, False):
+        ref, eng, (o, a, bound) = make_pair("sac", "hopper", 32, seed=9, crit_targ_update_freq=2)
+        eng.rb_fill_synthetic(300)
+        if ahead:
+            eng.instantiate_graphs()
+            assert eng.graph_kernel_count(2) > 0 and eng.graph_kernel_count(3) > 0 and eng.graph_kernel_count(4) == 0
+        eng.run_iterations(0, 6)
+        res.append((eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR)))
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
 
 
 def test_native_noise_stream_matches_philox_oracle():
