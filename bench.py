@@ -43,6 +43,84 @@ def describe(w):
             f"{'' if w['td3'] else '+alpha'} updates; one hipGraph launch per 3-iteration schedule period")
 
 
+def describe_short(w):
+    return (f"{'TD3' if w['td3'] else 'SAC'} {w['env']} batch={w['batch']} 2x256 MLP+LN, {w['rows']} rows in a {w['capacity']}-row HBM ring, "
+            f"1 critic update+Polyak per iteration, 2 actor{'' if w['td3'] else '+alpha'} updates every 3rd, hipGraph per 3 iterations")
+
+
+LINE_MAX = 1800           # the driver parses the LAST stdout line out of an 8 KB tail: the result line stays well under it
+DETAIL_FILE = "bench_detail.json"
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (bytes on the result line), everything else untouched"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _pick(d, keys, n=5):
+    return {k: _sig(d[k], n) for k in keys if d is not None and k in d}
+
+
+def result_line(full, w):
+    """The ONE line the driver parses (<= LINE_MAX bytes): the contract's keys, the roofline of the dominant kernel, the CPU
+    baseline, and three numbers per secondary config.  Everything else (node tables, per-grid rooflines, sweeps, full
+    configs) is in the side file `DETAIL_FILE` (written next to bench.py and, when it exists, into gpurun_out/)."""
+    out = {k: _sig(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data") if k in full}
+    out["config"] = {"workload": describe_short(w), "parallelism": full["config"]["parallelism"]}
+    for k in ("dry_run", "note"):
+        if k in full:
+            out[k] = full[k]
+    if "kernels_per_iteration" in full:
+        out["kernel_nodes_per_iteration"] = _sig(full["kernels_per_iteration"].get("average_per_iteration"), 4)
+    if "roofline" in full:
+        out["roofline"] = _pick(full["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algo_flops_per_launch",
+                                                   "algo_bytes_per_launch", "avg_launch_us", "share_of_node_time"), 4)
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"), 4)
+    for k in ("speedup_vs_eager_rocm", "speedup_vs_torch_cudagraph_rocm"):
+        if k in full:
+            out[k] = _sig(full[k], 4)
+    if "parity" in full:
+        out["parity_max_rel"] = _sig(full["parity"].get("max_rel"), 3)   # |engine - oracle| / max(|oracle|, 1), worst reported scalar
+    if "value_3000_steps" in full:
+        out["value_3000_steps"] = _pick(full["value_3000_steps"], ("median", "min", "max", "repeats"), 5)
+    if "replay_gather_hbm" in full:
+        out["replay_gather_hbm"] = _pick(full["replay_gather_hbm"], ("rows_per_launch", "achieved", "unit", "frac", "traffic"), 4)
+    if "configs" in full:
+        out["configs"] = {name: {"value": _sig(c["value"]), "ms_per_step": _sig(c["ms_per_step"]), "roofline_frac": _sig(c["roofline"]["frac"], 4),
+                                 "roofline_kernel": c["roofline"]["kernel"], "speedup_vs_eager_rocm": _sig(c.get("speedup_vs_eager_rocm"), 4)}
+                          for name, c in full["configs"].items()}
+    if "detail" in full:
+        out["detail"] = full["detail"]
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("replay_gather_hbm", "speedup_vs_torch_cudagraph_rocm", "kernel_nodes_per_iteration", "detail"):   # never expected: the
+        if len(line) <= LINE_MAX:                                                                                  # line is ~1.5 KB
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= LINE_MAX, len(line)
+    return line
+
+
+def write_detail(full):
+    """the full measurement record -> bench_detail.json beside bench.py (and a copy under gpurun_out/, which gpurun merges back)"""
+    paths = [os.path.join(ROOT, DETAIL_FILE)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_FILE))
+    done = []
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            done.append(os.path.relpath(path, ROOT))
+        except OSError:
+            pass
+    return done
+
+
 def gather_algo_bytes(o, a, batch):
     """2*B*T + 4*B, T = 4*(2o+a+1)+1 (s, a, r, s', one done byte; read once + write once; int32 index)."""
     return 2 * batch * (4 * (2 * o + a + 1) + 1) + 4 * batch
@@ -76,6 +154,20 @@ def run_steps(eng, it, n):
         eng.step(it % (DELAY + 1) == 0)
         it += 1
     return it
+
+
+def timed_windows(eng, it, steps=3000, repeats=5):
+    """SURVEY.md 8(d)'s protocol: `repeats` windows of `steps` iterations each (the engine already warm), every window bracketed
+    by a stream sync; returns (iteration number after, {"median", "min", "max", "repeats", "steps"} in gradient-steps/s)."""
+    vals = []
+    for _ in range(repeats):
+        eng.sync()
+        t0 = time.perf_counter()
+        it = run_steps(eng, it, steps)
+        eng.sync()
+        vals.append(steps / (time.perf_counter() - t0))
+    vals.sort()
+    return it, {"median": vals[len(vals) // 2], "min": vals[0], "max": vals[-1], "repeats": repeats, "steps": steps}
 
 
 # ------------------------------------------------------------------------------------------------ baselines (the oracle, timed)
@@ -208,7 +300,7 @@ def parity_deltas(w, device_id, iters=6):
             torch.randn(n, generator=g).numpy(), torch.randn(n, o, generator=g).numpy(), (torch.rand(n, generator=g) < 0.01).numpy()]
     for lo_ in range(0, n, 4096):
         eng.rb_extend(*[r[lo_:lo_ + 4096] for r in rows])
-    worst = {}
+    worst, worst_rel = {}, {}
     for i in range(iters):
         do_actor = i % (DELAY + 1) == 0
         eng.step(do_actor)
@@ -221,11 +313,13 @@ def parity_deltas(w, device_id, iters=6):
         got = eng.read_metrics()
         for k, v in want.items():
             worst[k] = max(worst.get(k, 0.0), abs(got[k] - float(v)))
+            worst_rel[k] = max(worst_rel.get(k, 0.0), abs(got[k] - float(v)) / max(abs(float(v)), 1.0))
     worst["params/critics"] = float(np.abs(eng.get_params(_lib.CRITICS) - flat_c(ref.qnets)).max())
     worst["params/actor"] = float(np.abs(eng.get_params(_lib.ACTOR) - flat_a(ref.actor)).max())
     eng.close()
     return {"path": "sactd3_step (fused iteration, graph replay, native RNG; oracle driven with the read-back indices and noise)",
-            "iterations": iters, "max_abs_delta": worst,
+            "iterations": iters, "max_abs_delta": worst, "max_rel_delta": worst_rel, "max_rel": max(worst_rel.values()),
+            "rel_definition": "|engine - oracle| / max(|oracle|, 1) per reported scalar, max over the iterations (north_star: within 1e-5)",
             "note": "fp32 vs the plain-PyTorch oracle; parameters after the Adam steps can differ by up to 2 lr per step where a "
                     "gradient is near zero (sign-like first steps), see tests/helpers.py"}
 
@@ -264,36 +358,47 @@ def node_budget(w, workload, device_id, ms_per_step, iters=200):
     eng.close()
     s0, s1 = sum(n["us"] for n in g0), sum(n["us"] for n in g1)
     per_iter = (DELAY * s0 + s1) / (DELAY + 1)
-    traffic = pmc_traffic(workload)
-    groups = {}
-    for weight, nodes in ((DELAY / (DELAY + 1), g0), (1.0 / (DELAY + 1), g1)):
-        for n in nodes:
-            key = (n["name"].split(":")[0], n["threads"])
-            d = groups.setdefault(key, dict(us_per_iteration=0.0, launches_per_iteration=0.0, flops=n["flops"], bytes=n["bytes"], roles=[]))
-            d["us_per_iteration"] += weight * n["us"]
-            d["launches_per_iteration"] += weight
-            role = n["name"].split(":", 1)[1]
-            if role not in d["roles"]:
-                d["roles"].append(role)
-    rooflines = []
-    for (kern, threads), d in sorted(groups.items(), key=lambda kv: -kv[1]["us_per_iteration"]):
-        us = d["us_per_iteration"] / d["launches_per_iteration"]
-        t_mfma, t_hbm = d["flops"] / (MFMA_F32_PEAK_TF * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
-        tr = traffic.get((kern, threads))
-        if t_mfma >= t_hbm:
-            ach, peak, unit, bound = d["flops"] / us * 1e-6, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
-        else:
-            ach, peak, unit, bound = d["bytes"] / us * 1e-3, HBM_PEAK_GBS, "GB/s", "hbm"
-        rooflines.append({"kernel": kern, "threads": threads, "roles": d["roles"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                          "frac": ach / peak, "traffic": tr["traffic"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                          "algo_flops_per_launch": d["flops"], "algo_bytes_per_launch": d["bytes"], "avg_launch_us": us,
-                          "launches_per_iteration": d["launches_per_iteration"], "us_per_iteration": d["us_per_iteration"],
-                          "share_of_node_time": d["us_per_iteration"] / per_iter})
+    by_name, by_grid = roofline_groups(g0, g1, pmc_traffic(workload), per_iter)
     return {"critic_only": [[n["name"], round(n["us"], 3)] for n in g0], "critic_plus_2_actor": [[n["name"], round(n["us"], 3)] for n in g1],
             "sum_critic_only_us": s0, "sum_critic_plus_2_actor_us": s1, "sum_per_iteration_us": per_iter,
             "measured_us_per_iteration": 1e3 * ms_per_step, "unaccounted_us_per_iteration": 1e3 * ms_per_step - per_iter,
             "note": "each node alone, back to back (includes its ~1.5 us launch boundary); unaccounted = what the dependent chain of "
-                    "DIFFERENT kernels and the gap between graph replays add or save"}, rooflines
+                    "DIFFERENT kernels and the gap between graph replays add or save"}, by_name, by_grid
+
+
+def roofline_groups(g0, g1, traffic, per_iter):
+    """Node tables of the critic-only (g0) and critic + actor (g1) iterations -> rooflines per kernel INSTANCE NAME (all grids
+    of one instance summed: how rocprofv3 --stats groups them; frac is FLOP- / byte-weighted = sum of work / sum of time) and,
+    for the side file, per (instance, grid).  Sorted by share of the iteration's node time: [0] is the dominant kernel."""
+    def build(keyf):
+        groups = {}
+        for weight, nodes in ((DELAY / (DELAY + 1), g0), (1.0 / (DELAY + 1), g1)):
+            for n in nodes:
+                d = groups.setdefault(keyf(n), dict(us=0.0, launches=0.0, flops=0.0, bytes=0.0, roles=[], grids=set()))
+                d["us"] += weight * n["us"]; d["launches"] += weight
+                d["flops"] += weight * n["flops"]; d["bytes"] += weight * n["bytes"]
+                d["grids"].add(n["threads"])
+                role = n["name"].split(":", 1)[1]
+                if role not in d["roles"]:
+                    d["roles"].append(role)
+        out = []
+        for key, d in sorted(groups.items(), key=lambda kv: -kv[1]["us"]):
+            kern = key[0] if isinstance(key, tuple) else key
+            us, L = d["us"] / d["launches"], d["launches"]
+            t_mfma, t_hbm = d["flops"] / (MFMA_F32_PEAK_TF * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
+            if t_mfma >= t_hbm:
+                ach, peak, unit, bound = d["flops"] / d["us"] * 1e-6, MFMA_F32_PEAK_TF, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = d["bytes"] / d["us"] * 1e-3, HBM_PEAK_GBS, "GB/s", "hbm"
+            trs = [traffic[(kern, g)] for g in sorted(d["grids"]) if (kern, g) in traffic]
+            calls = sum(t["calls"] for t in trs)
+            tr = sum(t["traffic"] * t["calls"] for t in trs) / calls if calls else None
+            out.append({"kernel": kern, "grids": sorted(d["grids"]), "roles": d["roles"], "bound": bound, "achieved": ach, "peak": peak,
+                        "unit": unit, "frac": ach / peak, "traffic": tr, "traffic_source": trs[0]["source"] if trs else None,
+                        "algo_flops_per_launch": d["flops"] / L, "algo_bytes_per_launch": d["bytes"] / L, "avg_launch_us": us,
+                        "launches_per_iteration": L, "us_per_iteration": d["us"], "share_of_node_time": d["us"] / per_iter})
+        return out
+    return build(lambda n: n["name"].split(":")[0]), build(lambda n: (n["name"].split(":")[0], n["threads"]))
 
 
 def kernel_counts(eng):
@@ -323,8 +428,8 @@ def baselines(w, value, cpu_seconds, eager_seconds, graph_seconds):
         if best is None or v > best[0]:
             best = (v, n, nt)
     out["cpu_baseline"] = {"value": best[0], "unit": "gradient-steps/s", "cores": best[2], "kind": "port",
-                           "sample": f"{best[1]} iterations of the same workload through oracle/sac_td3_ref.py "
-                                     f"(plain PyTorch CPU eager, torch.set_num_threads({best[2]}); faster of 1 and 8 threads)"}
+                           "sample": f"{best[1]} iterations of this workload, oracle/sac_td3_ref.py, PyTorch CPU eager, "
+                                     f"{best[2]} threads (faster of 1 and 8)"}
     v, n = oracle_rate(w, "cuda", eager_seconds)
     out["eager_rocm_baseline"] = {"value": v, "unit": "gradient-steps/s",
                                   "sample": f"{n} iterations, same restatement on cuda:0, eager PyTorch-ROCm, no graphs"}
@@ -341,21 +446,17 @@ def baselines(w, value, cpu_seconds, eager_seconds, graph_seconds):
 
 
 def secondary_config(name, device_id, steps=3000, warmup=300):
-    """BASELINE.json configs 3 / 4 in the same driver line: own engine, own timing, node budget, roofline, parity, baselines."""
-    import torch
+    """BASELINE.json configs 3 / 4, measured like the headline: own engine, median of 5 windows of 3000 iterations, node
+    budget, roofline, parity, baselines (the full objects go to the side file, three numbers each to the result line)."""
     w = WORKLOADS[name]
     eng = make_engine(w, seed=0, device_id=device_id)
     it = run_steps(eng, 0, warmup)
-    eng.sync(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(eng, it, steps)
-    eng.sync(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = {"workload": describe(w), "value": steps / dt, "unit": "gradient-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
-           "kernels_per_iteration": kernel_counts(eng),
+    it, win = timed_windows(eng, it, steps)
+    out = {"workload": describe(w), "value": win["median"], "value_windows": win, "unit": "gradient-steps/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 / win["median"], "kernels_per_iteration": kernel_counts(eng),
            "final_metrics": eng.read_metrics(), "replay_gather_cold": gather_cold(eng, w)}
     eng.close()
-    out["node_us"], rl = node_budget(w, name, device_id, out["ms_per_step"])
+    out["node_us"], rl, out["rooflines_per_grid"] = node_budget(w, name, device_id, out["ms_per_step"])
     out["roofline"], out["rooflines_top"] = rl[0], rl[1:5]
     out["parity"] = parity_deltas(w, device_id)
     out.update(baselines(w, out["value"], cpu_seconds=6.0, eager_seconds=3.0, graph_seconds=3.0))
@@ -487,7 +588,10 @@ def main():
             out.update(dry_run=True, value=None, note="no GPU work was done: rank launching / rendezvous / aggregation rehearsal only")
         elif not args.timed_only and world == 1:     # N > 1 lines carry the timed region only (roofline / cpu_baseline: N = 1)
             extras(out, eng, w, args, local, world)
-        print(json.dumps(out), flush=True)
+            out["detail"] = DETAIL_FILE
+            print("bench.py: full record (node tables, per-grid rooflines, sweeps, secondary configs) ->", ", ".join(write_detail(out)),
+                  file=sys.stderr, flush=True)
+        print(result_line(out, w), flush=True)
     if dist:
         dist.destroy_process_group()
 
@@ -498,11 +602,7 @@ def extras(out, eng, w, args, local, world):
     import numpy as np
     # a longer window of the same loop (the driver's 20-step window is ~1.7 ms): agreement check for `value`
     it = run_steps(eng, 0, 300)
-    eng.sync()
-    tp = time.perf_counter()
-    run_steps(eng, it, 3000)
-    eng.sync()
-    out["value_3000_steps"] = 3000 / (time.perf_counter() - tp)
+    it, out["value_3000_steps"] = timed_windows(eng, it, 3000, 5)
     out["replay_gather_cold"] = gather_cold(eng, w)
     # acting side (agents/agent.py:172-181): one predict round trip = H2D of the observations, 2 kernels, D2H + sync
     ob = np.zeros((4, w["o"]), np.float32)
@@ -570,7 +670,7 @@ def extras(out, eng, w, args, local, world):
     out["gather_batch_sweep"] = sweep
     eng.close()
     # roofline of the DOMINANT kernel of the timed graph (largest share of the iteration's node time), and the others
-    out["node_us"], rl = node_budget(w, args.workload, local, out["ms_per_step"])
+    out["node_us"], rl, out["rooflines_per_grid"] = node_budget(w, args.workload, local, out["ms_per_step"])
     out["roofline"], out["rooflines_top"] = rl[0], rl[1:5]
     # north_star's "replay-gather HBM GB/s as fraction of 8 TB/s": the same kernel on the Humanoid-v4 record
     # (3136 B/row) out of a full 1M-row (3.1 GB, far beyond the 256 MB Infinity Cache) ring, 65 536 rows per launch

@@ -115,6 +115,15 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["dry_run"] is True and d["value"] is None
     assert d["config"]["parallelism"].startswith("2 independent seeds")
+    assert lines[0] == out.stdout.splitlines()[-1] and len(lines[0]) < 1800      # the LAST stdout line, short enough for the driver's tail
+    # the N = 1 line (in-process, no rendezvous) and the N = 2 line carry the same keys, so a SCALE run parses like a BENCH run
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "7", "--warmup", "2", "--dry-run-ranks"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.splitlines()[-1])
+    contract = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config"}
+    assert contract <= set(d1) and set(d1) == set(d) and d1["n_gpus"] == 1 and set(d1["config"]) == set(d["config"])
 
 
 def test_sweep_launcher_starts_one_worker_per_gpu_and_shards_the_jobs(tmp_path):

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profiles on the GPU box: kernel stats + separate FETCH_SIZE / WRITE_SIZE passes of the timed loop of each workload,
-# summarised into profiles/ (run through gpurun from the repo root: `bash tools/gpu_profiles.sh r02`).
+# summarised into profiles/ (run through gpurun from the repo root: `bash tools/gpu_profiles.sh r03`).
 set -e
-R=${1:-r02}
+R=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT

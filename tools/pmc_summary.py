@@ -7,7 +7,11 @@
 
 Separate passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md, rocprofv3 PMC slots).  Units and
 corrections as that guide's HBM section prescribes: both counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes
-of wide coalesced reads, so fetch_bytes = 2 x 1024 x FETCH_SIZE; WRITE_SIZE is exact: write_bytes = 1024 x WRITE_SIZE.
+of 16-byte-per-lane coalesced reads, so fetch_bytes = 2 x 1024 x FETCH_SIZE for the kernels whose global loads are ALL
+dwordx4 (`fetch_factor` 2, column `loads` = "dwordx4"); a kernel that also fetches operands with 4-byte strided loads
+(MIXED below: k_nn's weight columns, the wide head backward, the dQ/da slice product) is outside what the guide calibrates:
+its FETCH_SIZE is taken as is (`fetch_factor` 1, `loads` = "mixed: uncalibrated"), which may understate it by up to 2x.
+WRITE_SIZE is exact: write_bytes = 1024 x WRITE_SIZE.
 Rows are grouped by (kernel instance, Grid_Size = total threads), which is how bench.py's node registry names a launch.
 """
 import argparse
@@ -16,6 +20,15 @@ import glob
 import os
 import re
 from collections import defaultdict
+
+
+# kernels (by name prefix) with 4-byte strided global loads beside their dwordx4 ones; every other k_* kernel of csrc/kernels.h
+# fetches with float4 (global_load_dwordx4) only -- tests/test_abi.py::test_fetch_width_table_matches_the_code_objects checks the ISA (share of non-dwordx4 load bytes)
+MIXED = ("k_nn", "k_actor_head_bwd", "k_ln_bwd<16>")        # exact instance names (no template arguments = a plain kernel)
+
+
+def fetch_factor(kernel):
+    return 1.0 if kernel in MIXED else 2.0
 
 
 def norm(name):
@@ -51,16 +64,17 @@ def main():
     with open(a.out, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["workload", "kernel", "threads", "calls", "FETCH_SIZE_kb_avg", "WRITE_SIZE_kb_avg", "fetch_bytes", "write_bytes",
-                    "traffic_bytes", "avg_us_profiled"])
+                    "traffic_bytes", "avg_us_profiled", "fetch_factor", "loads"])
         for key in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0, 0])[2])):
             f, x = fe.get(key, [0, 0.0, 0.0]), wr.get(key, [0, 0.0, 0.0])
             calls = max(f[0], x[0])
             if calls < a.min_calls or not key[0].startswith("k_"):
                 continue
             fk, wk = (f[1] / f[0] if f[0] else 0.0), (x[1] / x[0] if x[0] else 0.0)
-            fb, wb = 2.0 * 1024.0 * fk, 1024.0 * wk
+            ff = fetch_factor(key[0])
+            fb, wb = ff * 1024.0 * fk, 1024.0 * wk
             w.writerow([a.workload, key[0], key[1], calls, f"{fk:.3f}", f"{wk:.3f}", f"{fb:.0f}", f"{wb:.0f}", f"{fb + wb:.0f}",
-                        f"{(f[2] / f[0] if f[0] else x[2] / max(x[0], 1)):.2f}"])
+                        f"{(f[2] / f[0] if f[0] else x[2] / max(x[0], 1)):.2f}", f"{ff:.0f}", "dwordx4" if ff == 2.0 else "mixed: uncalibrated"])
     print("wrote", a.out)
 
 
