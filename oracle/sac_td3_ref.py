@@ -20,7 +20,13 @@ What it restates (paths relative to the reference checkout):
 
 Pinning status.  The three network classes are checked bit-for-bit against the
 *imported* reference ``agents/nets.py`` by ``tests/golden/make_golden.py`` (run
-in the build container, where ``/root/reference`` exists).  The agent-level
+in the build container, where ``/root/reference`` exists): init, forward,
+``get_action``, ``explore`` (``nets_ref_*.npz``) AND the backward pass --
+autograd gradients w.r.t. every parameter and the action input at the BASELINE
+batch sizes, of plain sums of the outputs and of the critic / actor losses of
+``agents/agent.py:216-233,272-281`` written with the reference's own modules
+(``nets_bwd_*.npz``; ``tests/test_golden.py`` requires bit equality on the CPU,
+``tests/test_gpu_engine.py`` drives the HIP kernels with the same data).  The agent-level
 update logic cannot be pinned the same way: ``agents/agent.py`` needs
 ``tensordict``/``torchrl``/``omegaconf``/``wandb`` which are absent, and the
 reference ships no tests or golden vectors -> for that part: PARITY UNPINNED

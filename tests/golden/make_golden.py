@@ -6,7 +6,15 @@
    itself disables with `python -O`) on fixed seeds / inputs.  tests/test_golden.py rebuilds the oracle's nets
    under the same seeds and must reproduce these numbers bit for bit -> pins oracle/sac_td3_ref.py's network
    classes (init, forward, get_action, explore) to the reference.
-2. `traj_*.npz`      -- a short injected-noise trajectory of the oracle agent (losses per iteration, parameter
+2. `nets_bwd_*.npz`  -- BACKWARD of the reference's own network classes at the BASELINE batch sizes (Hopper / HalfCheetah B = 256,
+   Humanoid B = 1024): autograd gradients, w.r.t. every parameter (and the action input), of (a) the plain functionals
+   `get_action(ob)["log_prob"].sum() + ["sample"].sum()`, `Critic(ob, ac).sum()`, `Actor(ob).sum()` and (b) the two losses the
+   update path differentiates, written with the reference's modules and the formulas of agents/agent.py:216-233 (twin MSE against
+   a given target) and :272-281 (`(alpha * logp - min Q).mean()`, TD3: `(-Q1).mean()`).  tests/test_golden.py requires the
+   oracle's classes to reproduce every stored number bit for bit on the CPU; tests/test_gpu_engine.py drives the HIP kernels
+   with the same parameters / inputs / noise and compares per key.  Large matrices are stored as every 8th row + float64 row and
+   column sums (inputs are regenerated from their seed; a float64 digest guards the regeneration).
+3. `traj_*.npz`      -- a short injected-noise trajectory of the oracle agent (losses per iteration, parameter
    digests).  agents/agent.py cannot be imported here (tensordict / torchrl / omegaconf / wandb are absent) and the
    reference ships no golden vectors, so these pin the ORACLE against regressions and give the GPU tests a
    committed target; they are not reference outputs (parity unpinned at agent level, see oracle/sac_td3_ref.py).
@@ -63,6 +71,109 @@ def make_nets_fixture(R):
         print("wrote nets_ref_%s.npz" % env)
 
 
+BWD_B = {"hopper": 256, "halfcheetah": 256, "humanoid": 1024}
+BWD_ALPHA = 0.2
+
+
+def bwd_inputs(env):
+    """the inputs of the backward fixtures, a function of the seed only (tests regenerate them; `digest` guards that)"""
+    o, a, bound = CASES[env]
+    B = BWD_B[env]
+    g = torch.Generator().manual_seed(321)
+    ob, ac = torch.randn(B, o, generator=g), (torch.rand(B, a, generator=g) * 2 - 1) * bound
+    y = torch.randn(B, generator=g)
+    torch.manual_seed(12)
+    eps = torch.empty(B, a).normal_()          # what Normal.rsample() draws under torch.manual_seed(12) (checked below)
+    digest = np.array([t.double().sum().item() for t in (ob, ac, y, eps)] + [t.double().abs().sum().item() for t in (ob, ac, y, eps)])
+    return ob, ac, y, eps, digest
+
+
+def pack_grad(out, name, t):
+    """full tensor when small; every 8th row + float64 row / column sums for the big matrices"""
+    t = t.detach()
+    if t.ndim == 2 and t.numel() > 8192:
+        out[name + "/rows8"] = t[::8].numpy()
+        out[name + "/rowsum"] = t.double().sum(1).numpy()
+        out[name + "/colsum"] = t.double().sum(0).numpy()
+    else:
+        out[name] = t.numpy()
+
+
+def bwd_functionals(make_sac, make_q, make_td3, env, out=None):
+    """Everything the backward fixtures hold, computed with the given network constructors (the reference's classes when the
+    fixture is generated, the oracle's when tests/test_golden.py checks it): returns {name: tensor} before packing."""
+    o, a, bound = CASES[env]
+    ob, ac, y, eps, digest = bwd_inputs(env)
+    res = {"digest": torch.from_numpy(digest)}
+    torch.manual_seed(11); actor = make_sac()
+    torch.manual_seed(13); q1 = make_q()
+    torch.manual_seed(14); pi = make_td3()
+    torch.manual_seed(16); q2 = make_q()
+    names = lambda m: [k for k, _ in m.named_parameters()]
+    # (a) plain functionals
+    torch.manual_seed(12)
+    act = actor.get_action(ob)
+    for k, gr in zip(names(actor), torch.autograd.grad(act["log_prob"].sum() + act["sample"].sum(), list(actor.parameters()))):
+        res[f"sum/actor/{k}"] = gr
+    res["sum/actor/sample"], res["sum/actor/log_prob"] = act["sample"].detach(), act["log_prob"].detach()
+    ac_r = ac.clone().requires_grad_(True)
+    gq = torch.autograd.grad(q1(ob, ac_r).sum(), list(q1.parameters()) + [ac_r])
+    for k, gr in zip(names(q1) + ["d_action"], gq):
+        res[f"sum/critic/{k}"] = gr
+    for k, gr in zip(names(pi), torch.autograd.grad(pi(ob).sum(), list(pi.parameters()))):
+        res[f"sum/td3/{k}"] = gr
+    # (b) the critic loss of agents/agent.py:216-233 against a given target y: sum over the twin of mse_loss(q.view(-1), y)
+    qs = [q(ob, ac) for q in (q1, q2)]
+    loss_q = sum(torch.nn.functional.mse_loss(qv.view(-1), y) for qv in qs)
+    gq = torch.autograd.grad(loss_q, list(q1.parameters()) + list(q2.parameters()))
+    for i, q in enumerate((q1, q2)):
+        for k, gr in zip(names(q), gq[i * len(names(q)):(i + 1) * len(names(q))]):
+            res[f"qloss/critic{i}/{k}"] = gr
+    res["qloss/q"], res["qloss/loss"] = torch.stack([qv.detach().view(-1) for qv in qs]), loss_q.detach()
+    # (b) the SAC actor loss of agents/agent.py:272-281: (alpha * logp - min_i Q_i(s, a_pi)).mean(), critics as constants
+    torch.manual_seed(12)
+    a_pi, logp, _ = actor.get_action(ob).values()
+    a_pi.retain_grad()
+    for q in (q1, q2):
+        for p_ in q.parameters():
+            p_.requires_grad_(False)
+    q_pi = torch.stack([q1(ob, a_pi), q2(ob, a_pi)])
+    loss_a = (BWD_ALPHA * logp - q_pi.min(0).values).mean()
+    ga = torch.autograd.grad(loss_a, list(actor.parameters()) + [a_pi])
+    for k, gr in zip(names(actor) + ["d_action"], ga):
+        res[f"aloss/sac/{k}"] = gr
+    res["aloss/sac/a_pi"], res["aloss/sac/logp"] = a_pi.detach(), logp.detach().view(-1)
+    res["aloss/sac/q_pi"], res["aloss/sac/loss"] = q_pi.detach().squeeze(-1), loss_a.detach()
+    # ... and TD3's: (-Q1(s, pi(s))).mean()
+    a_t = pi(ob)
+    a_t.retain_grad()
+    loss_t = (-q1(ob, a_t)).mean()
+    gt = torch.autograd.grad(loss_t, list(pi.parameters()) + [a_t])
+    for k, gr in zip(names(pi) + ["d_action"], gt):
+        res[f"aloss/td3/{k}"] = gr
+    res["aloss/td3/a_pi"], res["aloss/td3/loss"] = a_t.detach(), loss_t.detach()
+    # the noise: Normal.rsample() under seed 12 is mean + eps * std with eps = torch.empty(B, a).normal_() under the same seed
+    mean, std = actor(ob)
+    resample = torch.tanh(mean + eps * std) * actor.action_scale + actor.action_bias
+    assert torch.equal(resample.detach(), res["aloss/sac/a_pi"]), "rsample() noise is not the seed-12 normal_() draw"
+    res["eps"], res["y"] = eps, y
+    return res
+
+
+def make_bwd_fixture(R):
+    for env, (o, a, bound) in CASES.items():
+        mn, mx = torch.full((a,), -bound), torch.full((a,), bound)
+        res = bwd_functionals(lambda: R.TanhGaussActor((o,), (a,), (256, 256), mn, mx, layer_norm=True, device="cpu"),
+                              lambda: R.Critic((o,), (a,), (256, 256), layer_norm=True, device="cpu"),
+                              lambda: R.Actor((o,), (a,), (256, 256), mn, mx, exploration_noise=0.1, layer_norm=True, device="cpu"), env)
+        out = {}
+        for k, v in res.items():
+            pack_grad(out, k, v)
+        path = os.path.join(HERE, f"nets_bwd_{env}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote nets_bwd_%s.npz (%d arrays, %.0f KB)" % (env, len(out), os.path.getsize(path) / 1024))
+
+
 def run_traj(algo, env, B=32, iters=6, seed=5):
     from oracle.sac_td3_ref import Hps, RefAgent
     o, a, bound = CASES[env]
@@ -99,5 +210,7 @@ def make_traj_fixture():
 
 
 if __name__ == "__main__":
-    make_nets_fixture(reference_nets())
+    R = reference_nets()
+    make_nets_fixture(R)
+    make_bwd_fixture(R)
     make_traj_fixture()

@@ -32,7 +32,30 @@ def randomize_ln(agent, seed=1):
                 p.add_(0.01 * torch.randn(p.shape, generator=g))
 
 
-def assert_params_close(got, want, lr, steps, name="", atol=2e-5, rtol=1e-5, max_bad_frac=2e-3):
+# ---- observed parity deltas: tests report what they measured, the session writes it out (tests/conftest.py), and the
+# tolerances in the tests are set from these records (<= 2x the observed value, never above north_star's 1e-5 per step)
+OBSERVED = {}
+
+
+def observe(test, key, value):
+    """keep the LARGEST value seen for (test, key)"""
+    d = OBSERVED.setdefault(test, {})
+    d[key] = max(float(value), d.get(key, 0.0))
+
+
+def param_keys(in_dim, nh, ln, nets=1):
+    """[(name, start, stop)] over a flat parameter vector of `nets` networks back to back (sac-td3..._amd/schema.py order)"""
+    from sac_td3_cudagraphs_pytorch_amd import schema
+    out, off = [], 0
+    for n in range(nets):
+        for k, shp in schema.net_keys(in_dim, nh, ln):
+            size = int(np.prod(shp))
+            out.append((f"net{n}.{k}" if nets > 1 else k, off, off + size))
+            off += size
+    return out
+
+
+def assert_params_close(got, want, lr, steps, name="", atol=2e-5, rtol=1e-5, max_bad_frac=2e-3, layout=None, vec_bad=1, record=None):
     """Post-Adam parameter parity.
 
     Adam's early steps are sign-like (p -= lr * g / (|g| + eps')), so an element whose gradient
@@ -40,12 +63,34 @@ def assert_params_close(got, want, lr, steps, name="", atol=2e-5, rtol=1e-5, max
     direction that depends on summation order.  Those elements are legitimately unpredictable across
     implementations; everything else must agree tightly.  So: at most `max_bad_frac` of the elements
     may exceed (atol, rtol), and none may differ by more than 2 * lr * steps (+ atol).
+
+    With `layout` = (in_dim, n_head, layer_norm, nets) the check is made PER state_dict KEY: a weight matrix may
+    have `max_bad_frac` of its elements off, a vector (bias, LayerNorm affine, 1-row head) at most `vec_bad`
+    elements -- a global fraction would let every bias and LN vector of a net (about 1 % of its elements) step
+    the wrong way unnoticed.  `record` = test name: report the observed worst fractions (helpers.observe).
     """
     got = torch.as_tensor(got, dtype=torch.float32).reshape(-1).cpu()
     want = torch.as_tensor(want, dtype=torch.float32).reshape(-1).cpu()
     assert got.shape == want.shape, (name, got.shape, want.shape)
     diff = (got - want).abs()
     bad = diff > (atol + rtol * want.abs())
-    frac = bad.float().mean().item()
-    assert frac <= max_bad_frac, f"{name}: {frac:.2e} of elements off (max diff {diff.max().item():.3e})"
     assert diff.max().item() <= 2.0 * lr * steps + atol, f"{name}: max diff {diff.max().item():.3e}"
+    if layout is None:
+        frac = bad.float().mean().item()
+        assert frac <= max_bad_frac, f"{name}: {frac:.2e} of elements off (max diff {diff.max().item():.3e})"
+        return
+    keys = param_keys(*layout)
+    assert keys[-1][2] == got.numel(), (name, keys[-1][2], got.numel())
+    worst_mat, worst_vec = 0.0, 0
+    for k, lo, hi in keys:
+        nbad, n = int(bad[lo:hi].sum()), hi - lo
+        is_vec = k.endswith(("bias", "ln.weight")) or n <= 512
+        if is_vec:
+            worst_vec = max(worst_vec, nbad)
+            assert nbad <= vec_bad, f"{name} {k}: {nbad} of {n} elements off (max diff {diff[lo:hi].max().item():.3e})"
+        else:
+            worst_mat = max(worst_mat, nbad / n)
+            assert nbad / n <= max_bad_frac, f"{name} {k}: {nbad / n:.2e} of elements off (max diff {diff[lo:hi].max().item():.3e})"
+    if record:
+        observe(record, f"{name}: worst matrix bad fraction", worst_mat)
+        observe(record, f"{name}: worst vector bad count", worst_vec)

@@ -40,6 +40,38 @@ def test_oracle_nets_reproduce_reference_outputs(env):
         assert np.array_equal(pi.explore(ob).detach().numpy(), fx[f"td3_{tag}_explore"])
 
 
+def _unpacked(fx, name, t):
+    """(stored arrays, the same views of tensor t) for one fixture entry -- see make_golden.pack_grad"""
+    if name in fx.files:
+        return [(name, fx[name], t.numpy())]
+    return [(name + "/rows8", fx[name + "/rows8"], t[::8].numpy()), (name + "/rowsum", fx[name + "/rowsum"], t.double().sum(1).numpy()),
+            (name + "/colsum", fx[name + "/colsum"], t.double().sum(0).numpy())]
+
+
+@pytest.mark.parametrize("env", sorted(CASES))
+def test_oracle_nets_reproduce_reference_backward(env):
+    """tests/golden/nets_bwd_*.npz hold autograd gradients through the REFERENCE's own TanhGaussActor / Critic / Actor
+    (agents/nets.py:52-234) at the BASELINE batch sizes -- of log_prob.sum() + sample.sum(), Critic(ob, ac).sum(), Actor(ob).sum()
+    w.r.t. every parameter and the action input, and of the critic / actor losses of agents/agent.py:216-233,272-281 built
+    from those modules.  The oracle's classes, under the same seeds, must give the same numbers BIT FOR BIT: this pins the
+    oracle's backward (not only its forward) to the reference for rows A3 / A5 / A6 of SURVEY.md section 8."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    o, a, bound = CASES[env]
+    fx = np.load(os.path.join(HERE, "golden", f"nets_bwd_{env}.npz"))
+    mn, mx = torch.full((a,), -bound), torch.full((a,), bound)
+    res = mg.bwd_functionals(lambda: SquashedGaussPolicy(o, a, mn, mx, True), lambda: QNet(o, a, True),
+                             lambda: DetPolicy(o, a, mn, mx, 0.1, True), env)
+    seen = set()
+    for name, t in res.items():
+        for key, want, got in _unpacked(fx, name, t.detach()):
+            assert np.array_equal(got, want), (env, key, float(np.abs(got.astype(np.float64) - want).max()))
+            seen.add(key)
+    assert seen == set(fx.files) and len(seen) >= 100
+
+
 def _replay(fx, algo, env, drive):
     o, a, bound = CASES[env]
     B, seed = int(fx["B"]), int(fx["seed"])
