@@ -15,6 +15,9 @@
  *   - calls are asynchronous on the engine's HIP stream unless marked [sync];
  *   - one engine = one learner = one GPU; an engine is not thread-safe, different engines are.
  *   - all arithmetic is fp32, hidden width is 256 (agents/agent.py:56,101 hard-codes (256,256)).
+ *   - the library reads NO environment variable: every behaviour is a field of sactd3_config.  (Kernel-selection A/B switches
+ *     exist only in the separate tuning build, `make -C csrc tune` -> libsactd3_hip_tune.so, -DSACTD3_TUNING; they are listed in
+ *     csrc/engine.hip:create_impl and never compiled into libsactd3_hip.so -- tests/test_abi.py checks the shipped binary.)
  */
 #ifndef SACTD3_H
 #define SACTD3_H
@@ -203,7 +206,7 @@ int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* u
  * stale gradients): call it on a scratch engine.  Stands in for nothing in the reference: SURVEY.md 8d measurement. [sync] */
 int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, char* names, int names_cap,
                       float* usec, double* flops, double* bytes, int64_t* threads);
-/* run the replay gather at an arbitrary batch size (<= max set at create via env SACTD3_SWEEP_MAX_B) */
+/* run the replay gather at an arbitrary batch size (own scratch outputs, rows of the engine's ring): the bandwidth sweep of SURVEY.md 8d [sync] */
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes);
 
 #ifdef __cplusplus

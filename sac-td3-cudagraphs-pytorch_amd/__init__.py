@@ -10,5 +10,5 @@ name; ``/sac_td3_cudagraphs_pytorch_amd.py`` at the repo root aliases it).
 """
 from ._lib import EngineError, build_library, library_path, load_library  # noqa: F401
 from .engine import Config, Engine  # noqa: F401
-from .agent import Agent, BatchHandle, ReplayBuffer  # noqa: F401
+from .agent import Agent, BatchHandle, ReplayBuffer, StaleBatchError  # noqa: F401
 from . import launcher, loop  # noqa: F401

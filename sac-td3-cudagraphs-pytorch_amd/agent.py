@@ -50,18 +50,31 @@ class _DeviceScalar:
 _METRIC_SLOT = {"loss/qf_loss": 0, "loss/actor_loss": 1, "loss/alpha_loss": 2, "vitals/alpha": 3}   # SACTD3_M_*
 
 
+class StaleBatchError(RuntimeError):
+    """A BatchHandle names THE batch slot of the engine, not a copy: once a later `rb.sample()` (or a caller-owned batch) has
+    refilled the slot, an older handle no longer stands for the rows it was made for.  The reference's loop never keeps one
+    (orchestrator.py:338-348 samples, updates, drops); a caller that does gets this error instead of a silent update on the
+    newest sample."""
+
+
 class BatchHandle(dict):
     """What `rb.sample()` returns: the batch lives in the engine's HBM batch slot; indexing a key reads it back
     (host sync) as the reference's TensorDict keys would (observations, actions, rewards, next_observations,
     terminations, dones, index)."""
 
-    def __init__(self, engine: Engine):
+    def __init__(self, engine: Engine, generation: int = 0):
         super().__init__()
         self._engine = engine
+        self._generation = generation      # which rb.sample() filled the batch slot when this handle was made (see StaleBatchError)
         self._cache: Optional[Dict[str, np.ndarray]] = None
+
+    def _is_current(self) -> bool:
+        return getattr(self._engine, "_batch_generation", 0) == self._generation
 
     def __missing__(self, key):
         if self._cache is None:
+            if not self._is_current():
+                raise StaleBatchError("this batch handle is older than the engine's batch slot: a later rb.sample() / staged batch replaced its rows")
             self._cache = self._engine.read_batch()
             self._cache["terminations"] = self._cache["dones"]
             for k in ("rewards", "dones", "terminations"):
@@ -94,7 +107,8 @@ class ReplayBuffer:
         eng = self._need()
         assert batch_size == eng.cfg.batch_size, "the engine is built for one batch size (hps.batch_size)"
         eng.rb_sample()
-        return BatchHandle(eng)
+        eng._batch_generation = getattr(eng, "_batch_generation", 0) + 1
+        return BatchHandle(eng, eng._batch_generation)
 
     def __len__(self) -> int:
         return 0 if self._engine is None else self._engine.rb_len()
@@ -180,8 +194,16 @@ class Agent:
 
     # -- the hot path
     def _stage(self, batch) -> None:
-        if isinstance(batch, BatchHandle) or batch is None:
+        if batch is None:
+            return  # whatever is in the engine's batch slot
+        if isinstance(batch, BatchHandle):
+            if batch._engine is not self.engine:
+                raise StaleBatchError("this batch handle belongs to another agent's replay buffer")
+            if not batch._is_current():
+                raise StaleBatchError("update called with an old batch handle: the engine's batch slot holds a later sample "
+                                      "(keep the rows, e.g. dict(handle), to train on them again)")
             return  # already in the engine's batch slot
+        self.engine._batch_generation = getattr(self.engine, "_batch_generation", 0) + 1   # a caller-owned batch replaces the slot
         self.engine.load_batch(_np(batch["observations"]), _np(batch["actions"]), _np(batch["rewards"]),
                                _np(batch["next_observations"]), _np(batch["dones"]))
 
@@ -221,6 +243,7 @@ class Agent:
         reference's counters."""
         do_actor = i % (self.engine.cfg.actor_update_delay + 1) == 0
         self.engine.step(do_actor)
+        self.engine._batch_generation = getattr(self.engine, "_batch_generation", 0) + 1      # the fused step drew a new sample
         self.qnet_updates_so_far += 1
         if do_actor:
             self.actor_updates_so_far += self.engine.cfg.actor_update_delay
@@ -293,6 +316,21 @@ class Agent:
         f = lambda key: np.concatenate([st[i][key].detach().cpu().numpy().astype(np.float32).reshape(max(stacked, 1), -1) for i in idx], 1).reshape(-1)
         return f("exp_avg"), f("exp_avg_sq"), int(round(float(st[idx[0]]["step"])))
 
+    @staticmethod
+    def compare_hps(saved: Mapping[str, Any], current: Mapping[str, Any]) -> Dict[str, Dict[str, Any]]:
+        """agents/agent.py:373-401 (`compare_dictconfigs`): depth-1 comparison of two configs -> {"added", "removed", "changed"}
+        (`added`: keys only the current config has; `removed`: keys only the saved one has; `changed`: {"from": saved, "to": current})."""
+        diff: Dict[str, Dict[str, Any]] = {"added": {}, "removed": {}, "changed": {}}
+        k1, k2 = set(saved.keys()), set(current.keys())
+        for k in sorted(k2 - k1):
+            diff["added"][k] = current[k]
+        for k in sorted(k1 - k2):
+            diff["removed"][k] = saved[k]
+        for k in sorted(k1 & k2):
+            if saved[k] != current[k]:
+                diff["changed"][k] = {"from": saved[k], "to": current[k]}
+        return diff
+
     def load_from_disk(self, path: Path) -> None:
         """agents/agent.py:360-371.  Reads files written by `save` above and any file in the reference's schema that a
         weights-only loader accepts (state_dicts + optimiser state_dicts of tensors and builtin scalars).  A .pth written
@@ -300,6 +338,13 @@ class Agent:
         and this loader is deliberately not loosened."""
         import torch
         ck = torch.load(path, weights_only=True)
+        # the reference compares the saved run's config with the current one and reports added / removed / changed keys before
+        # it loads (agents/agent.py:411-415, there against the wandb run's config); here against the checkpoint's own `hps`
+        self.last_hps_diff = self.compare_hps(ck["hps"], self._plain_hps()) if isinstance(ck.get("hps"), dict) else None
+        if self.last_hps_diff and any(self.last_hps_diff.values()):
+            import warnings
+            d = self.last_hps_diff
+            warnings.warn(f"checkpoint hps differ from this agent's -- added: {d['added']}  removed: {d['removed']}  changed: {d['changed']}")
         if "timesteps_so_far" in ck:
             self.timesteps_so_far = ck["timesteps_so_far"]
         actor = schema.dict_to_flat(ck["actor"], self.ob_dim, self._nh(), self.ln)

@@ -123,7 +123,7 @@ struct sactd3_engine {
   int64_t rb_len = 0, rb_cursor = 0, qnet_updates = 0;
   hipGraphExec_t graphs[G_COUNT] = {}; int graph_nodes[G_COUNT] = {};
   std::vector<hipGraphExec_t> predict_graphs;   // [explore][n]: the two launches of sactd3_predict, captured per row count
-  // tuning aids, read from the environment ONCE at create (SACTD3_KS / SACTD3_NT / SACTD3_TN_KT); 0 = the built-in choice
+  // kernel-selection knobs: fixed defaults in the shipped library; tuning builds (-DSACTD3_TUNING) read them from the environment at create
   int tune_ks = 0, tune_nt = 0, tune_tn_kt = 0, tune_pad64 = 0, tune_tn64_min = 0, tune_rows4 = 0, tune_nn16 = 0, tune_xr = -1;
   // node registry of the enqueue_* sequences (sactd3_time_nodes): every kernel launch of the path goes through
   // node_on(), which numbers it; with node_only >= 0 only that launch is issued (the others are skipped), with
@@ -1035,24 +1035,31 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   HIPCHK(hipSetDevice(c.device_id));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, c.device_id));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SACTD3_ALLOW_ANY_ARCH"))
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return e->fail(SACTD3_ENODEV, "device is not gfx950 (this library carries gfx950 code objects only)");
   e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  // tuning aids: read once here, never on a launch path
+  // kernel-selection defaults (what the shipped library always runs): 4-row single-wave k_critic_tail / k_ln_bwd below B = 1024
+  // (-1.0 us per Hopper iteration, +-0 at Humanoid); the split-M weight-gradient route from half a chip's worth of 64 x 32 tiles
+  e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;
+  e->tune_tn64_min = e->num_cus / 2;
+#ifdef SACTD3_TUNING
+  // A/B switches of the tuning builds ONLY (`make tune` -> libsactd3_hip_tune.so, used by tools/ab_*.py / tools/ab_iter.sh through
+  // SACTD3_LIBRARY): the shipped library reads no environment variable at all.  Read once here, never on a launch path.
+  //   SACTD3_KS 1|2|4 / SACTD3_NT 1 / SACTD3_TN_KT 1|2: block shapes of k_nt / k_tn;  SACTD3_PAD64: dynamic-LDS pad of k_nt64;
+  //   SACTD3_NN16 1: k_nn instead of k_nn64;  SACTD3_XR -1|0|1|2|4|8: XCD tile placement (-1 = least-fetch split per launch);
+  //   SACTD3_TN64_MIN: tiles x nets from which the split-M route is taken;
+  //   SACTD3_ROWS4: bit mask.  1 / 2: the 4-row single-wave k_critic_tail / k_ln_bwd.  The other bits turn a default OFF:
+  //   4 k_actor_head_bwd_s, 16 the policy-pass merge for wide observations, 32 the in-kernel replay gather of the wide opening trunk,
+  //   128 k_nt64_ln in the 4-net trunk (-> k_ln_fwd + k_nt64), 256 k_nt64_ln<2,2,1> for the 1- / 2-net second layers (-> k_nt).
   if (const char* f = getenv("SACTD3_KS")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) e->tune_ks = v; }
   if (const char* f = getenv("SACTD3_NT")) { if (atoi(f) == 1) e->tune_nt = 1; }
   if (const char* f = getenv("SACTD3_PAD64")) e->tune_pad64 = atoi(f);
   if (const char* f = getenv("SACTD3_NN16")) e->tune_nn16 = atoi(f);
-  if (const char* f = getenv("SACTD3_XR")) e->tune_xr = atoi(f);      // XCD tile placement: -1 (default) = least-fetch split per launch, 0 = row-major
-  // SACTD3_ROWS4: bit mask of kernel-selection switches, for full-iteration A/B runs (tools/ab_iter.sh).  1 / 2: the 4-row single-wave
-  // k_critic_tail / k_ln_bwd (default ON below B = 1024).  The other bits turn a default OFF: 4 k_actor_head_bwd_s, 16 the policy-pass
-  // merge for wide observations, 32 the in-kernel replay gather of the wide opening trunk, 128 k_nt64_ln in the 4-net trunk (-> k_ln_fwd
-  // + k_nt64), 256 k_nt64_ln<2,2,1> for the 1- / 2-net second layers (-> k_nt).
+  if (const char* f = getenv("SACTD3_XR")) e->tune_xr = atoi(f);
   if (const char* f = getenv("SACTD3_ROWS4")) e->tune_rows4 = atoi(f);
-  else e->tune_rows4 = c.batch_size < BIG_BATCH ? 3 : 0;   // 4-row (single-wave) k_critic_tail / k_ln_bwd below B = 1024: -1.0 us per Hopper iteration, +-0 at Humanoid
-  e->tune_tn64_min = e->num_cus / 2;
   if (const char* f = getenv("SACTD3_TN64_MIN")) e->tune_tn64_min = atoi(f);
   if (const char* f = getenv("SACTD3_TN_KT")) { const int v = atoi(f); if (v == 1 || v == 2) e->tune_tn_kt = v; }
+#endif
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
   e->o = c.ob_dim; e->a = c.ac_dim; e->B = c.batch_size;
@@ -1471,11 +1478,13 @@ int sactd3_step(sactd3_engine* e, int do_actor) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step: buffer is empty");
-  e->qnet_updates += 1;
-  const bool polyak = e->cfg.prefer_td3_over_sac || (e->qnet_updates % e->cfg.crit_targ_update_freq == 0);
+  const int64_t updates = e->qnet_updates + 1;     // (the engine's own counter advances only once the iteration has been launched)
+  const bool polyak = e->cfg.prefer_td3_over_sac || (updates % e->cfg.crit_targ_update_freq == 0);
   const bool act = do_actor != 0 && e->cfg.actor_update_delay > 0;
   const int which = G_STEP00 + (act ? 2 : 0) + (polyak ? 1 : 0);
-  return run_graph(e, which, [&](hipStream_t s) { return enqueue_step(e, s, act, polyak); });
+  RCCHK(run_graph(e, which, [&](hipStream_t s) { return enqueue_step(e, s, act, polyak); }));
+  e->qnet_updates = updates;
+  return 0;
 }
 
 // One period of the actor schedule (orchestrator.py:345-349: iteration i with i % (delay + 1) == 0 runs the actor updates,
@@ -1489,12 +1498,13 @@ int sactd3_step_period(sactd3_engine* e) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   if (!td3 && e->cfg.crit_targ_update_freq != 1) return e->fail(SACTD3_ESTATE, "step_period: needs crit_targ_update_freq == 1");
   const int n = e->cfg.actor_update_delay + 1;
-  e->qnet_updates += n;
-  return run_graph(e, G_PERIOD, [&](hipStream_t s) {
+  RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) {
     for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n));
     if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
     return 0;
-  });
+  }));
+  e->qnet_updates += n;
+  return 0;
 }
 
 // Capture + instantiate the graphs of sactd3_step (both schedules, with the target update) and sactd3_step_period now instead of

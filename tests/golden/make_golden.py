@@ -89,9 +89,9 @@ def bwd_inputs(env):
 
 
 def pack_grad(out, name, t):
-    """full tensor when small; every 8th row + float64 row / column sums for the big matrices"""
+    """full tensor, except the gradients of the big weight matrices: every 8th row + float64 row / column sums"""
     t = t.detach()
-    if t.ndim == 2 and t.numel() > 8192:
+    if t.ndim == 2 and t.numel() > 8192 and name.endswith(".weight"):
         out[name + "/rows8"] = t[::8].numpy()
         out[name + "/rowsum"] = t.double().sum(1).numpy()
         out[name + "/colsum"] = t.double().sum(0).numpy()

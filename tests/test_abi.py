@@ -112,6 +112,19 @@ def test_no_serialised_operand_loads():
         assert hit and all("L" * batch in s for s in hit), (key, hit)
 
 
+def test_shipped_library_reads_no_environment_switches():
+    """include/sactd3.h: every behaviour of libsactd3_hip.so is a field of sactd3_config; the kernel-selection A/B switches
+    (SACTD3_KS, SACTD3_ROWS4, ...) and the any-arch override exist only in the tuning build (-DSACTD3_TUNING)."""
+    import sac_td3_cudagraphs_pytorch_amd as pkg
+    blob = open(os.path.join(os.path.dirname(pkg.__file__), "libsactd3_hip.so"), "rb").read()
+    for name in (b"SACTD3_KS", b"SACTD3_NT", b"SACTD3_ROWS4", b"SACTD3_XR", b"SACTD3_TN64_MIN", b"SACTD3_TN_KT", b"SACTD3_PAD64", b"SACTD3_NN16",
+                 b"SACTD3_ALLOW_ANY_ARCH"):
+        assert name not in blob, name
+    src = open(os.path.join(ROOT, "sac-td3-cudagraphs-pytorch_amd", "csrc", "engine.hip")).read()
+    outside = re.sub(r"#ifdef SACTD3_TUNING.*?#endif", "", src, flags=re.S)
+    assert "getenv" not in outside
+
+
 def test_fetch_width_table_matches_the_code_objects():
     """tools/pmc_summary.py doubles rocprofv3's FETCH_SIZE (gfx950 tallies 16-byte-per-lane reads at half, MI355X_MICROARCH.md, HBM)
     only for kernels whose operand fetches are all global_load_dwordx4; its MIXED table names the kernels with 4-byte strided

@@ -174,6 +174,42 @@ def test_checkpoint_carries_the_reference_optimizer_keys(tmp_path, algo):
     assert np.array_equal(other.engine.get_params(_lib.CRITICS_TARGET), other.engine.get_params(_lib.CRITICS))   # targets = clones (agents/agent.py:64,107)
 
 
+def test_update_with_an_old_batch_handle_is_refused():
+    """agents/agent.py:183,244 take the batch as an argument; here a handle names the engine's batch slot, so an update called with
+    a handle from BEFORE the latest rb.sample() must fail loudly rather than train on the newest rows."""
+    agent, o, a = _agent("sac", B=32, cap=400)
+    agent.rb.extend({"observations": torch.randn(300, o), "actions": torch.rand(300, a) * 2 - 1, "rewards": torch.randn(300),
+                     "next_observations": torch.randn(300, o), "dones": torch.zeros(300, dtype=torch.bool)})
+    old = agent.rb.sample(32)
+    new = agent.rb.sample(32)
+    with pytest.raises(P.StaleBatchError):
+        agent.update_qnets(old)
+    with pytest.raises(P.StaleBatchError):
+        agent.update_actor(old)
+    agent.update_qnets(new); agent.update_actor(new)           # the current handle works, for both updates (orchestrator.py:341,348)
+    rows = {k: np.array(new[k]) for k in ("observations", "actions", "rewards", "next_observations", "dones")}
+    agent.iteration(0)                                         # the fused step draws its own sample: `new` is stale now
+    with pytest.raises(P.StaleBatchError):
+        agent.update_qnets(new)
+    agent.update_qnets(rows)                                   # a caller-owned copy of the rows is always accepted
+    assert np.isfinite(float(agent.engine.read_metrics()["loss/qf_loss"]))
+
+
+def test_load_reports_hps_differences_like_the_reference(tmp_path):
+    """agents/agent.py:411-415 warns with added / removed / changed config keys before loading; load_from_disk does the same
+    against the checkpoint's own `hps` (a different gamma / lr must not pass silently)."""
+    agent, o, a = _agent("sac", B=32, cap=200)
+    path = agent.save(tmp_path, sfx="h")
+    same, _, _ = _agent("sac", B=32, cap=200)
+    same.load_from_disk(path)
+    assert same.last_hps_diff == {"added": {}, "removed": {}, "changed": {}}
+    other, _, _ = _agent("sac", B=32, cap=200, gamma=0.9, qnets_lr=5e-4)
+    with pytest.warns(UserWarning, match="gamma"):
+        other.load_from_disk(path)
+    ch = other.last_hps_diff["changed"]
+    assert ch["gamma"] == {"from": pytest.approx(0.99), "to": pytest.approx(0.9)} and "qnets_lr" in ch
+
+
 def test_load_refuses_a_resume_blob_of_another_shape(tmp_path):
     agent, o, a = _agent("sac", B=32, cap=200)
     path = agent.save(tmp_path, sfx="x")

@@ -60,3 +60,43 @@ def test_config_from_reference_yaml_keys():
     assert c.alpha_init == pytest.approx(0.2) and c.crit_targ_update_freq == 1
     cc = c.to_c()
     assert cc.ob_dim == 17 and cc.ac_dim == 6 and cc.abi_version == 1 and cc.qnets_lr == pytest.approx(3e-4)
+
+
+def test_compare_hps_reports_added_removed_changed_like_the_reference():
+    """agents/agent.py:373-401 `compare_dictconfigs` (depth 1): added = only in the current config, removed = only in the saved one,
+    changed = {"from": saved, "to": current}."""
+    saved = {"gamma": 0.99, "polyak": 0.005, "actor_lr": 3e-4, "wandb_project": "x"}
+    cur = {"gamma": 0.98, "polyak": 0.005, "actor_lr": 3e-4, "clip_norm": 0.5}
+    d = P.Agent.compare_hps(saved, cur)
+    assert d == {"added": {"clip_norm": 0.5}, "removed": {"wandb_project": "x"}, "changed": {"gamma": {"from": 0.99, "to": 0.98}}}
+    assert P.Agent.compare_hps(cur, cur) == {"added": {}, "removed": {}, "changed": {}}
+
+
+def test_batch_handle_goes_stale_when_the_slot_is_refilled():
+    """A BatchHandle names the engine's ONE batch slot: after a later rb.sample() an older handle is refused (StaleBatchError)
+    instead of silently standing for the newest sample.  (Host logic only: a stub engine counts the calls.)"""
+    class StubEngine:
+        def __init__(self):
+            self.cfg = SimpleNamespace(batch_size=4)
+            self.samples = 0
+
+        def rb_sample(self):
+            self.samples += 1
+
+        def rb_len(self):
+            return 10
+
+        def read_batch(self):
+            return {k: np.full((4, 1), self.samples, np.float32) for k in ("observations", "actions", "rewards", "next_observations", "dones", "index")}
+
+    rb = P.ReplayBuffer(100)
+    rb._bind(StubEngine())
+    first = rb.sample(4)
+    assert first._is_current() and float(first["observations"][0, 0]) == 1.0
+    second = rb.sample(4)
+    assert second._is_current() and not first._is_current()
+    assert float(first["observations"][0, 0]) == 1.0          # rows already read back stay readable (they are host copies)
+    third = rb.sample(4)
+    with pytest.raises(P.StaleBatchError):
+        second["observations"]                                 # never read while current: its rows are gone
+    assert float(third["rewards"][0, 0]) == 3.0
