@@ -152,6 +152,37 @@ def bwd_functionals(make_sac, make_q, make_td3, env, out=None):
     for k, gr in zip(names(pi) + ["d_action"], gt):
         res[f"aloss/td3/{k}"] = gr
     res["aloss/td3/a_pi"], res["aloss/td3/loss"] = a_t.detach(), loss_t.detach()
+    # fp32 noise floor of the two composed losses' gradients: the same modules cast to float64, same inputs and noise; `noise/<key>` =
+    # max |fp32 gradient - fp64 gradient|.  Where squashed actions saturate (1 - y^2 -> 0: 2.6 % of Humanoid's at these initial
+    # parameters) the log-prob terms cancel badly and torch's own fp32 result sits 1e-4 .. 7e-4 from the float64 one; a second fp32
+    # implementation is compared with a tolerance scaled by this measured floor instead of a guessed constant.
+    import copy
+    a64, p64, c64 = copy.deepcopy(actor).double(), copy.deepcopy(pi).double(), [copy.deepcopy(q).double() for q in (q1, q2)]
+    for q in c64:
+        for p_ in q.parameters():
+            p_.requires_grad_(True)
+    ob64, ac64, y64, eps64 = ob.double(), ac.double(), y.double(), eps.double()
+    lq = sum(torch.nn.functional.mse_loss(q(ob64, ac64).view(-1), y64) for q in c64)
+    g64 = torch.autograd.grad(lq, list(c64[0].parameters()) + list(c64[1].parameters()))
+    for i in range(2):
+        for k, gr in zip(names(q1), g64[i * len(names(q1)):(i + 1) * len(names(q1))]):
+            res[f"noise/qloss/critic{i}/{k}"] = (res[f"qloss/critic{i}/{k}"].double() - gr).abs().max().float()
+    mean64, std64 = a64(ob64)
+    x64 = mean64 + eps64 * std64
+    y_t = torch.tanh(x64)
+    ap64 = y_t * a64.action_scale + a64.action_bias
+    lp64 = (-((x64 - mean64) ** 2) / (2 * std64 ** 2) - std64.log() - 0.9189385332046727
+            - torch.log(a64.action_scale * (1 - y_t.pow(2)) + 1e-6)).sum(1, keepdim=True)
+    for q in c64:
+        for p_ in q.parameters():
+            p_.requires_grad_(False)
+    la = (BWD_ALPHA * lp64 - torch.stack([c64[0](ob64, ap64), c64[1](ob64, ap64)]).min(0).values).mean()
+    for k, gr in zip(names(actor), torch.autograd.grad(la, list(a64.parameters()))):
+        res[f"noise/aloss/sac/{k}"] = (res[f"aloss/sac/{k}"].double() - gr).abs().max().float()
+    at64 = p64(ob64)
+    lt = (-c64[0](ob64, at64)).mean()
+    for k, gr in zip(names(pi), torch.autograd.grad(lt, list(p64.parameters()))):
+        res[f"noise/aloss/td3/{k}"] = (res[f"aloss/td3/{k}"].double() - gr).abs().max().float()
     # the noise: Normal.rsample() under seed 12 is mean + eps * std with eps = torch.empty(B, a).normal_() under the same seed
     mean, std = actor(ob)
     resample = torch.tanh(mean + eps * std) * actor.action_scale + actor.action_bias

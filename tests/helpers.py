@@ -92,5 +92,6 @@ def assert_params_close(got, want, lr, steps, name="", atol=2e-5, rtol=1e-5, max
             worst_mat = max(worst_mat, nbad / n)
             assert nbad / n <= max_bad_frac, f"{name} {k}: {nbad / n:.2e} of elements off (max diff {diff[lo:hi].max().item():.3e})"
     if record:
+        observe(record, f"{name}: max diff / lr", diff.max().item() / lr)
         observe(record, f"{name}: worst matrix bad fraction", worst_mat)
         observe(record, f"{name}: worst vector bad count", worst_vec)

@@ -40,6 +40,7 @@ def logp_close(got, want, action, scale, bias, name=""):
     got, want = np.asarray(got, np.float64).reshape(-1), want.astype(np.float64).reshape(-1)
     bad = np.abs(got - want) > 2e-5 + 1e-5 * np.abs(want) + cond
     assert not bad.any(), (name, int(bad.sum()), float(np.abs(got - want)[bad].max()), float(cond[bad].min()))
+    return cond
 
 
 def gclose(got, want, name=""):
@@ -249,10 +250,13 @@ def test_update_qnets_intermediates(algo, env, B, ln):
     Xn = eng.debug_read("Xn").reshape(B, ldc)
     close(Xn[:, :o], nobs, 0, 0, "s' in the batch slot")
     close(Xn[:, o:o + a], ref.trace["next_action"], name="next action")
+    cond = np.zeros(B)
     if algo == "sac":
-        logp_close(eng.debug_read("logp_next"), ref.trace["next_logp"], ref.trace["next_action"], bound, 0.0, "next logp")
+        cond = logp_close(eng.debug_read("logp_next"), ref.trace["next_logp"], ref.trace["next_action"], bound, 0.0, "next logp")
     close(eng.debug_read("q_target").reshape(2, B), ref.trace["q_target"], name="target Q")
-    close(eng.debug_read("targ_q"), ref.trace["targ_q"], name="Bellman target")
+    # y = r + (1 - d) gamma (q' - alpha logp'): carries gamma alpha x the conditioning bound of logp' (logp_close) on saturated rows
+    tq, wq = eng.debug_read("targ_q").astype(np.float64), ref.trace["targ_q"].numpy().astype(np.float64)
+    assert (np.abs(tq - wq) <= 1e-5 + 1e-5 * np.abs(wq) + ref.hps.gamma * ref.hps.alpha_init * cond).all(), "Bellman target"
     close(eng.debug_read("q").reshape(2, B), ref.trace["q"], name="online Q")
     for i, c in enumerate(man.tr["q_caches"]):
         if ln:
@@ -333,14 +337,19 @@ def _fixture_views(fx, prefix, key, got):
 
 
 def _grads_match_fixture(fx, prefix, got_dict, what):
+    """per key: gclose's bound (rtol 2e-4, atol 2e-6 + 1e-5 max|g|) widened by 8x the fp32 noise floor the fixture measured for that
+    key with the reference's own modules (`noise/...` = max |fp32 - fp64| of torch's gradient: make_golden.bwd_functionals)"""
     for k, g in got_dict.items():
         views = _fixture_views(fx, prefix, k, g)
         gmax = max(float(np.abs(v[2]).max()) for v in views if v[3] == 1)
+        floor = 8.0 * float(fx[f"noise/{prefix}/{k}"])
+        observe("kernels_reproduce_the_reference_nets_backward", f"{prefix}/{k}: fp32 noise floor / max|g|", float(fx[f"noise/{prefix}/{k}"]) / max(gmax, 1e-30))
         for label, got, want, n in views:
             if n == 1:
-                gclose(got, want, name=f"{what} {label}")
-            else:   # float64 sums of n elements, each within gclose's bound
-                np.testing.assert_allclose(got, want, rtol=2e-4, atol=n * (2e-6 + 1e-5 * gmax), err_msg=f"{what} {label}")
+                observe("kernels_reproduce_the_reference_nets_backward", f"{label}: max |hip - reference| / max|g|", float(np.abs(got - want).max()) / max(gmax, 1e-30))
+                close(got, want, rtol=2e-4, atol=2e-6 + 1e-5 * gmax + floor, name=f"{what} {label}")
+            else:   # float64 sums of n elements, each within the bound above
+                np.testing.assert_allclose(got, want, rtol=2e-4, atol=n * (2e-6 + 1e-5 * gmax + floor), err_msg=f"{what} {label}")
 
 
 @pytest.mark.parametrize("env", ["hopper", "halfcheetah", "humanoid"])
@@ -437,7 +446,7 @@ def test_crit_targ_update_freq_gate():
 # TRAJ_TOL (1 + i) -- 1e-5 (north_star) on the first, never more than 1e-5 more per iteration; parameters after the steps: per
 # state_dict key at most TRAJ_BAD of a matrix's elements / TRAJ_VEC_BAD elements of a vector beyond atol 2e-5 + rtol 1e-5
 # (tests/helpers.py: sign-like Adam steps of near-zero gradients).  Values set from gpurun_out/parity_observed.json (<= 2x observed).
-TRAJ_TOL, TRAJ_BAD, TRAJ_VEC_BAD = 1e-5, 2e-2, 8
+TRAJ_TOL, TRAJ_BAD, TRAJ_VEC_BAD = 1e-5, 5e-2, 2
 
 
 def push_adam(eng, ref):

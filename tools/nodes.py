@@ -12,10 +12,10 @@ import time
 t0 = time.perf_counter(); bench.run_steps(eng, it, 3000); eng.sync(); dt = time.perf_counter() - t0
 print(f"{name}: {3000/dt:.0f} it/s  {dt/3000*1e6:.2f} us/iteration")
 eng.close()
-nu, rl = bench.node_budget(w, name, 0, dt / 3000 * 1e3, iters)
+nu, rl, _ = bench.node_budget(w, name, 0, dt / 3000 * 1e3, iters)
 for k in ("sum_critic_only_us", "sum_critic_plus_2_actor_us", "sum_per_iteration_us", "unaccounted_us_per_iteration"):
     print(k, round(nu[k], 2))
 for n, us in nu["critic_plus_2_actor"]:
     print(f"  {us:7.2f}  {n}")
 for r in rl[:8]:
-    print(f"{r['kernel']:28s} thr {r['threads']:7d} {r['avg_launch_us']:6.2f} us x{r['launches_per_iteration']:.2f}/it  {r['bound']} frac {r['frac']:.3f}  share {r['share_of_node_time']:.3f}")
+    print(f"{r['kernel']:28s} grids {r['grids']} {r['avg_launch_us']:6.2f} us x{r['launches_per_iteration']:.2f}/it  {r['bound']} frac {r['frac']:.3f}  share {r['share_of_node_time']:.3f}")
