@@ -347,32 +347,35 @@ def pmc_traffic(workload):
 
 
 def node_budget(w, workload, device_id, ms_per_step, iters=200):
-    """DESIGN.md section 5's budget as numbers: every kernel node of the 7- and 30-node iteration graphs timed alone
+    """DESIGN.md section 5's budget as numbers: every kernel node of the period graph (and of the single-iteration graphs) timed alone
     (HIP events on the engine's stream, un-profiled, back-to-back launches of that node on a scratch engine), the sum over
     the reference's schedule (2 critic-only iterations + 1 with the actor updates per period) against the measured
     ms_per_step, and the roofline of every kernel instance from its algorithmic FLOPs / bytes."""
     eng = make_engine(w, seed=12345, device_id=device_id)
     run_steps(eng, 0, 6)
     eng.sync()
-    g0, g1 = eng.time_nodes(False, iters), eng.time_nodes(True, iters)
+    g0, g1, gp = eng.time_nodes(0, iters), eng.time_nodes(1, iters), eng.time_nodes(2, iters)
     eng.close()
-    s0, s1 = sum(n["us"] for n in g0), sum(n["us"] for n in g1)
-    per_iter = (DELAY * s0 + s1) / (DELAY + 1)
-    by_name, by_grid = roofline_groups(g0, g1, pmc_traffic(workload), per_iter)
-    return {"critic_only": [[n["name"], round(n["us"], 3)] for n in g0], "critic_plus_2_actor": [[n["name"], round(n["us"], 3)] for n in g1],
+    s0, s1, sp = sum(n["us"] for n in g0), sum(n["us"] for n in g1), sum(n["us"] for n in gp)
+    # the timed loop replays the PERIOD graph (one iteration with the actor updates + DELAY critic-only ones; for SAC the critic-only
+    # iterations' sampling and next-action passes run ahead inside the first one's launches): its nodes are the budget
+    per_iter = sp / (DELAY + 1)
+    by_name, by_grid = roofline_groups([(1.0 / (DELAY + 1), gp)], pmc_traffic(workload), per_iter)
+    return {"period_of_3_iterations": [[n["name"], round(n["us"], 3)] for n in gp], "sum_period_us": sp,
+            "critic_only": [[n["name"], round(n["us"], 3)] for n in g0], "critic_plus_2_actor": [[n["name"], round(n["us"], 3)] for n in g1],
             "sum_critic_only_us": s0, "sum_critic_plus_2_actor_us": s1, "sum_per_iteration_us": per_iter,
             "measured_us_per_iteration": 1e3 * ms_per_step, "unaccounted_us_per_iteration": 1e3 * ms_per_step - per_iter,
             "note": "each node alone, back to back (includes its ~1.5 us launch boundary); unaccounted = what the dependent chain of "
                     "DIFFERENT kernels and the gap between graph replays add or save"}, by_name, by_grid
 
 
-def roofline_groups(g0, g1, traffic, per_iter):
-    """Node tables of the critic-only (g0) and critic + actor (g1) iterations -> rooflines per kernel INSTANCE NAME (all grids
-    of one instance summed: how rocprofv3 --stats groups them; frac is FLOP- / byte-weighted = sum of work / sum of time) and,
-    for the side file, per (instance, grid).  Sorted by share of the iteration's node time: [0] is the dominant kernel."""
+def roofline_groups(parts, traffic, per_iter):
+    """parts = [(launches per iteration of each node, node table)] -> rooflines per kernel INSTANCE NAME (all grids of one instance
+    summed: how rocprofv3 --stats groups them; frac is FLOP- / byte-weighted = sum of work / sum of time) and, for the side file,
+    per (instance, grid).  Sorted by share of the iteration's node time: [0] is the dominant kernel."""
     def build(keyf):
         groups = {}
-        for weight, nodes in ((DELAY / (DELAY + 1), g0), (1.0 / (DELAY + 1), g1)):
+        for weight, nodes in parts:
             for n in nodes:
                 d = groups.setdefault(keyf(n), dict(us=0.0, launches=0.0, flops=0.0, bytes=0.0, roles=[], grids=set()))
                 d["us"] += weight * n["us"]; d["launches"] += weight

@@ -199,7 +199,8 @@ int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph);
  * measured with hipEvents on the engine's stream: "gather" (a fresh index draw per launch), "polyak", "trunk_critics" (the 4-net
  * hidden-layer launch of update_qnets; on wide inputs it is two launches). [sync] */
 int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec);
-/* Per-node device time of one fused iteration (sactd3_step with this do_actor): every kernel launch of the sequence
+/* Per-node device time of one fused iteration (sactd3_step with this do_actor; do_actor == 2: of one whole period as
+ * sactd3_step_period captures it): every kernel launch of the sequence
  * alone, `iters` times back to back between two HIP events on the engine's stream.  Returns the node count n (<= max_nodes)
  * and fills usec[n], flops[n] (2 x MACs of the GEMMs in the launch), bytes[n] (operands + results, each once),
  * threads[n] (grid x block, rocprofv3's Grid_Size); `names` receives n newline-terminated "kernel-instance:role" strings.  Consumes the learner's state (optimiser steps repeat on

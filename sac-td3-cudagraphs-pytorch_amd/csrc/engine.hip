@@ -109,6 +109,12 @@ struct sactd3_engine {
   float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
   float* a_z2n = nullptr;        // layer-2 output of the s' pass when the pi(s) pass shares its launch
+  float* a_z2m = nullptr;        // ... of a second s' pass that runs ahead (pipelined period, see BatchSlot)
+  // Batch slots.  Slot 0 is THE batch slot (X, Xn, rew, done, idx, logp_n, eps of the critic site above); a pipelined period graph
+  // (sactd3_step_period, SAC) samples and runs the next-action pass of its critic-only iterations AHEAD, inside the last actor
+  // update's launches -- the actor does not change in between -- into slots 1 and 2, which those iterations then train on.
+  struct BatchSlot { float *X, *Xn, *rew, *done, *logp_n, *eps_c; int* idx; } bs[3] = {};
+  int cur_slot = 0;              // the slot the most recent iteration trained on (what read_batch / read_noise / debug_read report)
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
   float* s_h1 = nullptr;         // large-batch path: layer-1 activations of nets whose caller keeps no copy ([4][B][256])
@@ -210,11 +216,12 @@ static unsigned gather_blocks(long chunks) {
   const long one = (chunks + 255) / 256;
   return (unsigned)(one <= 4096 ? one : (chunks + 256L * GATHER_CPT - 1) / (256L * GATHER_CPT));
 }
-static GatherArgs gather_args(sactd3_engine* e, const float* ring, int identity_len) {
+static GatherArgs gather_args(sactd3_engine* e, const float* ring, int identity_len, int slot = 0, int ctr_add = 0) {
   GatherArgs g{};
-  g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = e->idx;
-  g.X = (float4*)e->X; g.Xn = (float4*)e->Xn; g.rew = e->rew; g.done = e->done;
-  g.B = e->B; g.len_override = identity_len;
+  const sactd3_engine::BatchSlot& S = e->bs[slot];
+  g.ring = (const float4*)ring; g.rec4 = e->rec4; g.cx = e->cx; g.cn = e->cn; g.ctl = e->ctl; g.idx = S.idx;
+  g.X = (float4*)S.X; g.Xn = (float4*)S.Xn; g.rew = S.rew; g.done = S.done;
+  g.B = e->B; g.len_override = identity_len; g.ctr_add = ctr_add;
   g.rec4_magic = magic_div((unsigned)e->rec4, (unsigned long long)e->B * e->rec4 + 1);
   const long chunks = (long)e->B * e->rec4;
   g.cpb = (int)((chunks + 256L * gather_blocks(chunks) - 1) / (256L * gather_blocks(chunks)));
@@ -261,7 +268,7 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
   double by = 4.0 * ((double)nets * g.N * (g.K + 3) + (double)nets * g.M * g.N);
   by += fuse1 ? 4.0 * ((double)nets * HID * (g.K1 + 1) + (double)(nets / g.npg) * g.M * g.K1) : 4.0 * (double)nets * g.M * g.K;
   for (int i = 0; i < nets / g.npg; ++i) by += 4.0 * g.npg * (double)g.M * HID * ((g.g[i].xh_out ? 1 : 0) + (g.g[i].h_out ? 1 : 0));
-  if (g.gblocks) by += 8.0 * (double)g.ga.B * 4 * (g.ga.cx + g.ga.cn + 1);
+  if (g.gblocks) by += (g.gblocks / std::max(g.gb_each, 1)) * 8.0 * (double)g.ga[0].B * 4 * (g.ga[0].cx + g.ga[0].cn + 1);
   if (pro == 0) {
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)nets);
     if (!node_on(e, "k_nt_wide.layer1", fl, by, grid, dim3(256))) return 0;
@@ -281,7 +288,7 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     // unfused launches read whole input rows: place the tiles so that an XCD pulls few rows and few weight columns (the fused
     // form's input rows are a few dozen bytes: it keeps one weight column tile per XCD, the row-major numbering)
     gg.xr = fuse1 ? 0 : pick_xr(e, (g.M + rb - 1) / rb, tiles_n / nt, 4.0 * g.M * g.K, 4.0 * g.N * g.K);
-    const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0);
+    const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0) + (gg.nz_n > 2 ? gg.nz[2].blocks : 0);
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + gg.alpha_block + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
     if (e->node_log) {
@@ -440,11 +447,15 @@ static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] 
 // The two hidden layers of MLP trunks: z2 = relu(LN(x W1^T + b1)) W2^T + b2 for up to two groups of nets
 // (a group = nets sharing an input and a parameter arena) in ONE launch.  One kernel when the input is narrow
 // (first layer recomputed per output tile), two otherwise.  Optional stores of layer 1's xhat / h / rstd.
-struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; int ring_off = 0; };
-struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr; bool fuse_gather = false;
+// ring: the group's rows are read from the replay ring (field offset ring_off) -- the sample drawn with sample_ctr + sctr_add
+struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; int ring_off = 0;
+                  bool ring = false; int sctr_add = 0; const int* ring_idx = nullptr; };
+struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr;
+                    int ngather = 0; GatherArgs gather[2] = {};   // replay gathers into batch slots riding as extra blocks (launches with ring groups)
                     const AlphaArgs* alpha = nullptr;      // alpha: a pending temperature step to carry as one extra block
-                    int nnoise = 0; NoiseJob noise[2] = {}; bool* noise_taken = nullptr;      // the following tail's draws (see NoiseJob)
+                    int nnoise = 0; NoiseJob noise[3] = {}; bool* noise_taken = nullptr;      // the following tail's draws (see NoiseJob)
                     int force_ks = 0;                      // keep the single-net launch's K split (bit-equal results across launch shapes)
+                    bool no_tiled64 = false;               // keep the 32 x 32-tile launches (the ones that can read ring rows / carry gathers)
                     int* tick0b = nullptr; float* adam_out_b = nullptr; double* adam_pw_b = nullptr; float lr_b = 0.f; };   // a second step counter
 static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M, const NetLayout& L, long p_ns,
                          int ngrp, int npg, const TrunkGrp* grp, TrunkTicks tk) {
@@ -456,10 +467,20 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.g[i].P = grp[i].P; h.g[i].Y = grp[i].z2; h.g[i].xh_out = grp[i].xh; h.g[i].h_out = grp[i].h; h.g[i].rstd_out = grp[i].rstd;
   }
   const int nets = ngrp * npg;
-  const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4;
-  if (tk.alpha && big_path) {   // the k_nt launches (fused, or the layer-2 one below) carry it as an extra block; the tiled form has none: own node, first
-    LAUNCH("k_alpha_step", 0.0, 4.0 * M, k_alpha_step, dim3(1), dim3(256), *tk.alpha);
-  }
+  const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4 && !tk.no_tiled64;
+  auto set_ring = [&](NtArgs& a) {   // which groups read their rows from the replay ring, and the gathers that ride along
+    for (int i = 0; i < ngrp; ++i) { a.g[i].ring = grp[i].ring ? 1 : 0; a.g[i].ring_off = grp[i].ring_off; a.g[i].sctr_add = grp[i].sctr_add; a.g[i].ring_idx = grp[i].ring_idx; }
+    a.ga[0] = tk.ngather > 0 ? tk.gather[0] : gather_args(e, e->ring, -1);     // (ring groups take the ring / control block from ga[0])
+    if (tk.ngather > 1) a.ga[1] = tk.gather[1];
+    a.gb_each = tk.ngather > 0 ? (int)gather_blocks((long)e->B * e->rec4) : 0;
+    a.gblocks = tk.ngather * a.gb_each;
+  };
+  auto set_noise = [&](NtArgs& a) {  // the draws of the tail(s) that follow ride in this launch as a few extra blocks
+    if (tk.nnoise <= 0) return;
+    a.nz_n = tk.nnoise; a.nz_ctl = e->ctl;
+    for (int i = 0; i < tk.nnoise; ++i) { a.nz[i] = tk.noise[i]; a.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
+    if (tk.noise_taken) *tk.noise_taken = true;
+  };
   // MFMA-bound sizes with enough 64 x 64 tiles to fill the chip: tiled GEMM -> LayerNorm row kernel -> tiled GEMM
   if (big_path) {
     NtArgs g{};
@@ -470,8 +491,12 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     g.tick0b = tk.tick0b; g.adam_out_b = tk.adam_out_b; g.adam_pw_b = tk.adam_pw_b; g.lr_b = tk.lr_b;
     const dim3 grid((unsigned)(((M + 63) / 64) * (HID / 64) * nets));
     const double by_w = 4.0 * nets * (double)HID, by_rows = 4.0 * nets * (double)M * HID;
-    LAUNCH_DYN("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
-               (k_nt64<4, 2, 2>), grid, dim3(512), e->tune_pad64, g);
+    {   // a pending temperature step rides as one extra block of the first-layer launch (nothing in the trunk reads log_alpha)
+      dim3 grid1 = grid;
+      if (tk.alpha) { g.alpha_block = 1; g.al = *tk.alpha; g.nt_blocks = (int)grid.x; grid1.x += 1; }
+      LAUNCH_DYN("k_nt64<4,2,2>.layer1", 2.0 * nets * (double)M * HID * K, by_w * (K + 1) + 4.0 * ngrp * (double)M * K + by_rows,
+                 (k_nt64<4, 2, 2>), grid1, dim3(512), e->tune_pad64, g);
+    }
     if (e->tune_rows4 & 128) {   // (A/B: the separate LayerNorm row kernel between the two tiled GEMMs)
       LnFwd l{};
       l.npg = npg; l.oG = L.g1; l.oBe = L.be1; l.p_ns = p_ns; l.B = M; l.ln = e->cfg.layer_norm;
@@ -513,16 +538,8 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
     h.tick0 = tk.tick0; h.tick1 = tk.tick1; h.adam_out = tk.adam_out; h.adam_pw = tk.adam_pw; h.lr = tk.lr; h.b1 = e->cfg.adam_beta1; h.b2 = e->cfg.adam_beta2;
     h.w1_magic = magic_div((unsigned)L.ld1, 4u * HID * (unsigned)L.ld1);
     if (tk.alpha) { h.alpha_block = 1; h.al = *tk.alpha; }
-    if (tk.nnoise > 0) {   // the draws of the tail that follows ride in this launch as a few extra blocks
-      h.nz_n = tk.nnoise; h.nz_ctl = e->ctl;
-      for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
-      if (tk.noise_taken) *tk.noise_taken = true;
-    }
-    if (tk.fuse_gather) {   // x = the s' field of the sampled records; extra blocks fill the batch slot (see NtArgs)
-      h.ring_rows = 1; h.ga = gather_args(e, e->ring, -1);
-      for (int i = 0; i < ngrp; ++i) h.g[i].ring_off = grp[i].ring_off;
-      h.gblocks = (int)gather_blocks((long)e->B * e->rec4);
-    }
+    set_noise(h);
+    set_ring(h);            // x = a field of the sampled records; extra blocks fill the batch slot(s) (see NtArgs)
     h.tick0b = tk.tick0b; h.adam_out_b = tk.adam_out_b; h.adam_pw_b = tk.adam_pw_b; h.lr_b = tk.lr_b;
     return launch_nt(e, s, "layers1+2", pro, true, h, nets, tk.force_ks);
   }
@@ -534,12 +551,9 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   g.tick0b = tk.tick0b; g.adam_out_b = tk.adam_out_b; g.adam_pw_b = tk.adam_pw_b; g.lr_b = tk.lr_b;
   if (M >= BIG_BATCH && M == e->B) {   // large batch, too few nets for 64 x 64 tiles to fill the chip: 32 x 32 LDS-tiled form
     unsigned nblk = (unsigned)(((M + 31) / 32) * (HID / 32) * nets);
-    if (tk.fuse_gather) {   // x = the field of the sampled records itself; extra blocks fill the batch slot (as in the fused k_nt form)
-      g.ring_rows = 1; g.ga = gather_args(e, e->ring, -1);
-      for (int i = 0; i < ngrp; ++i) g.g[i].ring_off = grp[i].ring_off;
-      g.gblocks = (int)gather_blocks((long)e->B * e->rec4); g.nt_blocks = (int)nblk;
-      nblk += (unsigned)g.gblocks;
-    }
+    set_ring(g);            // x = the field of the sampled records itself; extra blocks fill the batch slot(s) (as in the fused k_nt form)
+    g.nt_blocks = (int)nblk;
+    nblk += (unsigned)g.gblocks;
     const dim3 grid(nblk);
     LAUNCH("k_nt64<2,2,1>.layer1", 2.0 * nets * (double)M * HID * K, 4.0 * (nets * (double)HID * (K + 1) + ngrp * (double)M * K + nets * (double)M * HID),
            (k_nt64<2, 2, 1>), grid, dim3(256), g);
@@ -547,15 +561,11 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   for (int i = 0; i < ngrp; ++i) h.g[i].in = grp[i].z1;
   h.ld_in = HID; h.in_ns = (long)M * HID;
   if (tk.alpha) { h.alpha_block = 1; h.al = *tk.alpha; }   // (never together with noise blocks: those read the counter it ticks)
-  if (tk.nnoise > 0) {   // (as in the fused form) the following tail's draws as extra blocks of the layer-2 launch
-    h.nz_n = tk.nnoise; h.nz_ctl = e->ctl;
-    for (int i = 0; i < tk.nnoise; ++i) { h.nz[i] = tk.noise[i]; h.nz[i].blocks = (tk.noise[i].n + 1023) / 1024; }
-    if (tk.noise_taken) *tk.noise_taken = true;
-  }
+  set_noise(h);            // (as in the fused form) the following tail's draws as extra blocks of the layer-2 launch
   if (M >= BIG_BATCH && M == e->B && !(e->tune_rows4 & 256)) {   // large batch: the 32 x 32 LDS-tiled form with the LayerNorm prologue
     h.ln_pro = e->cfg.layer_norm ? 1 : 0;
     h.nt_blocks = ((M + 31) / 32) * (HID / 32) * nets;
-    const int nzb = (h.nz_n > 0 ? h.nz[0].blocks : 0) + (h.nz_n > 1 ? h.nz[1].blocks : 0);
+    const int nzb = (h.nz_n > 0 ? h.nz[0].blocks : 0) + (h.nz_n > 1 ? h.nz[1].blocks : 0) + (h.nz_n > 2 ? h.nz[2].blocks : 0);
     double st = 0.0;
     for (int i = 0; i < ngrp; ++i) st += ((grp[i].xh ? 1.0 : 0.0) + (grp[i].h ? 1.0 : 0.0)) / ngrp;
     LAUNCH("k_nt64_ln<2,2,1>.layer2", 2.0 * nets * (double)M * HID * HID, 4.0 * nets * ((double)HID * (HID + 3) + (double)M * HID * (2.0 + st)),
@@ -642,15 +652,20 @@ static bool opening_trunk_carries_alpha(const sactd3_engine* e) {
 // *policy_done tells the caller whether that happened.
 // actor_targ_rides: (TD3, fused iteration without actor updates) the actor target's Polyak update as extra blocks of the
 // weight-gradient launch; *actor_targ_done reports whether the launch could carry it.
+// slot / pre_sampled: (pipelined period, SAC) the batch slot this update trains on; pre_sampled = its sample, gather and next-action
+// pass (a', log pi(a'|s')) were already produced ahead by the last actor update of the period's first iteration (enqueue_update_actor,
+// `ahead`): the update starts at the twin-critic trunk, which then carries the step-counter tick and a deferred temperature step.
 static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ,
-                                bool with_policy = false, bool* policy_done = nullptr, bool actor_targ_rides = false, bool* actor_targ_done = nullptr) {
+                                bool with_policy = false, bool* policy_done = nullptr, bool actor_targ_rides = false, bool* actor_targ_done = nullptr,
+                                int slot = 0, bool pre_sampled = false) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
+  const sactd3_engine::BatchSlot& S = e->bs[slot];
   int ctr_owed = 0;
   // target action: SAC a' ~ pi(s') with the ONLINE actor (agent.py:205); TD3 pi_targ(s') + clipped noise (agent.py:194-200)
   const float* Pact = td3 ? e->Ta : e->Pa;
-  {
+  if (!pre_sampled) {
     const bool in_kernel_gather = fused_sample && opening_trunk_gathers(e);
     // the FIRST actor update's pi(s) pass rides along (see enqueue_step): in the fused-first-layer launches of narrow observations,
     // and as a second group of the layer-by-layer launches of wide ones at large batch (Humanoid: two nodes fewer per actor iteration)
@@ -658,13 +673,16 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     const bool merge_policy = with_policy && ((in_kernel_gather && e->o <= 64) || wide_merge);
     e->node_role = fused_sample ? (merge_policy ? "critic/next-action+sample & actor0/policy" : "critic/next-action+sample") : "critic/next-action";
     // (layer-by-layer launches materialise z1: the target-action group borrows the target critics' z1 slab, idle until the next launch)
-    TrunkGrp g[2] = {{e->Xn, Pact, wide_merge ? e->t_z1 : e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
-                     {e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
+    TrunkGrp g[2] = {{S.Xn, Pact, wide_merge ? e->t_z1 : e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
+                     {S.X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
-    tk.fuse_gather = in_kernel_gather;
+    if (in_kernel_gather) {   // the trunk reads its rows from the ring itself; the gather into the batch slot rides along
+      tk.ngather = 1; tk.gather[0] = gather_args(e, e->ring, -1, slot);
+      for (auto& gg : g) { gg.ring = true; gg.ring_idx = S.idx; }
+    }
     const int mode = td3 ? (c.targ_actor_smoothing ? 1 : 0) : 0;
     bool eps_ready = false;
-    if (!td3 || mode == 1) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise_taken = &eps_ready; }
+    if (!td3 || mode == 1) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_CRITIC, 0u, 0, B); tk.noise[tk.nnoise - 1].eps = S.eps_c; tk.noise_taken = &eps_ready; }
     // a temperature step deferred from the previous iteration of the same graph (sactd3_step_period) rides in this launch; its
     // tick of the noise counter is owed: this iteration's draws count one ahead and the critics' last kernel ticks by two
     int owed = 0;
@@ -682,19 +700,20 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
     }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, merge_policy ? 2 : 1, 1, g, tk));
-    ActorTail t = tail_args(e, merge_policy ? e->a_z2n : e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, e->Xn, e->ldc, e->o, e->logp_n);
+    ActorTail t = tail_args(e, merge_policy ? e->a_z2n : e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
+    t.eps = S.eps_c;
     t.eps_ready = eps_ready; t.ctr_add = owed;
     if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
     if (merge_policy && tail_rows_per_block(t) == 4) {
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
+      t1.obs_src = S.X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
       const int nb = (B + 3) / 4;
       LAUNCH("k_actor_tail_s2<4>", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
              k_actor_tail_s2<4>, dim3(2 * nb), dim3(64), t, t1, nb);
       if (policy_done) *policy_done = true;
     } else if (merge_policy) {                  // (wide heads: the two tails as one launch of the general kernel)
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-      t1.obs_src = e->X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;
+      t1.obs_src = S.X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;
       const int nb = (B + 15) / 16;
       LAUNCH("k_actor_tail2", 2.0 * 2 * B * (double)HID * t.L.nh, 4.0 * ((double)B * HID * 4 + 2.0 * t.L.nh * (HID + 1) + 4.0 * HID + (double)B * (6 * e->a + 4 + 2 * e->o)),
              k_actor_tail2, dim3(2 * nb), dim3(256), t, t1, nb);
@@ -704,16 +723,22 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
   {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232).
      // (Measured: running the online pair on a fork/join side branch of the graph instead costs +30 us per replay on
      //  ROCm 7.2 -- cross-stream edges are far dearer than the 1.7 us of a linear edge -- so graphs stay linear.)
-    const TrunkGrp g[2] = {{e->Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
-                           {e->X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
+    const TrunkGrp g[2] = {{S.Xn, e->Tc, e->t_z1, e->t_z2, nullptr, nullptr, nullptr},
+                           {S.X, e->Pc, e->c_z1, e->c_z2, e->c_xh1, e->c_h1, e->c_rs1}};
     e->node_role = "critic/twin-q(2 target + 2 online)";
-    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, TrunkTicks{nullptr, nullptr, nullptr, nullptr, 0.f}));
+    TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+    if (pre_sampled) {   // this launch opens the update: the critics' step counter + Adam scalars, and a temperature step deferred from the
+                         // period's first iteration (its tick of the noise counter is made up by this update's last kernel)
+      tk.tick0 = &e->ctl->t_q; tk.adam_out = e->ctl->adam_q; tk.adam_pw = e->ctl->pw_q; tk.lr = c.qnets_lr;
+      if (e->alpha_pending && e->alpha_tick_owed) { tk.alpha = &e->pending_alpha; e->alpha_pending = false; e->alpha_tick_owed = false; ctr_owed = 1; }
+    }
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, tk));
   }
   e->node_role = "critic/loss+backward";
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
-    t.rew = e->rew; t.done = e->done; t.logp_next = e->logp_n; t.log_alpha = e->la;
+    t.rew = S.rew; t.done = S.done; t.logp_next = S.logp_n; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.pstride = e->nblk4;
     if (e->tune_rows4 & 1) LAUNCH("k_critic_tail<4>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<4>, dim3(e->nblk4, 2), dim3(64), t);
@@ -741,7 +766,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     const int nb_tail = (e->tune_rows4 & 1) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
     if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[0], 1, e->Lc.be2, nb_tail); }
     tn_fin(g.pr[0], 2, e->Lc.Wh, nb_tail); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = nb_tail;
-    g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, e->X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
+    g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, S.X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
     if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[1], 4, e->Lc.be1, nb_ln); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
@@ -766,8 +791,12 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
 // kernel that applies the step (agents/agent.py:331 after :286)
 // defer_alpha: (last actor update of an iteration that is followed by another one in the same graph) leave the temperature step
 // to the next iteration's opening launch
+// ahead: (pipelined period, SAC with autotune, last actor update of the period's first iteration) the sampling, gather and
+// next-action pass a' ~ pi(s') of the `ahead` critic-only iterations that follow, into batch slots 1 .. ahead: the actor does not
+// change any more before they run, so their passes ride in this update's last trunk / tail launches (the temperature draw's) as
+// extra groups -- those iterations then start at their twin-critic trunk (enqueue_update_qnets, pre_sampled).
 static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false, float* polyak_targ = nullptr,
-                                bool defer_alpha = false) {
+                                bool defer_alpha = false, int ahead = 0) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
@@ -882,14 +911,40 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
       t.eps_ready = eps_ready;
       RCCHK(launch_tail(e, s, t));
     } else if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
-      const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr};
+      TrunkGrp g[3] = {{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr}, {}, {}};
       TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
       bool eps_ready = false;
       tk.nnoise = 1; tk.noise[0] = noise_job(e, sb_l, 32u, 0, B); tk.noise_taken = &eps_ready;
-      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
+      float* z2k[2] = {e->a_z2n, e->a_z2m};
+      for (int k = 1; k <= ahead; ++k) {
+        // iteration k of the period: its sample is the one drawn with sample_ctr + (k - 1) (the counter already counts this
+        // iteration's), its critic-site draws those of noise counter + k (one tick by this iteration's deferred temperature step,
+        // one per critic update in between) -- exactly what that iteration's own opening launches would have used
+        const sactd3_engine::BatchSlot& S = e->bs[k];
+        g[k] = TrunkGrp{S.Xn, e->Pa, e->t_z1 + (size_t)(k - 1) * BH, z2k[k - 1], nullptr, nullptr, nullptr, e->ldc};
+        g[k].ring = true; g[k].sctr_add = k - 1; g[k].ring_idx = S.idx;
+        tk.gather[tk.ngather++] = gather_args(e, e->ring, -1, k, k - 1);
+        tk.noise[tk.nnoise] = noise_job(e, SACTD3_SITE_CRITIC, 0u, k, B); tk.noise[tk.nnoise++].eps = S.eps_c;
+      }
+      if (ahead) { tk.force_ks = 4; tk.no_tiled64 = true; e->node_role = (j & 1) ? "actor1/alpha & next-action passes ahead" : "actor0/alpha & next-action passes ahead"; }
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1 + ahead, 1, g, tk));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
       t.eps_ready = eps_ready;
-      RCCHK(launch_tail(e, s, t));
+      if (!ahead) RCCHK(launch_tail(e, s, t));
+      else {
+        ActorTail tn[2];
+        for (int k = 1; k <= 2; ++k) {
+          const sactd3_engine::BatchSlot& S = e->bs[std::min(k, ahead)];
+          tn[k - 1] = tail_args(e, z2k[std::min(k, ahead) - 1], e->Pa, B, 0, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
+          tn[k - 1].eps = S.eps_c; tn[k - 1].eps_ready = eps_ready; tn[k - 1].ctr_add = std::min(k, ahead);
+        }
+        t.tick = &e->ctl->sample_ctr; t.tick_add = ahead - 1;      // every reader of the index streams (the trunk launch above) is done
+        const int rpb = tail_rows_per_block(t), nb = (B + rpb - 1) / rpb, nb2 = ahead > 1 ? nb : 0;
+        const double fl = 2.0 * (1 + ahead) * B * (double)HID * t.L.nh;
+        const double by = 4.0 * (1 + ahead) * ((double)B * HID + (double)t.L.nh * (HID + 1) + 2.0 * HID + (double)B * (3 * e->a + 2));
+        if (rpb == 4) LAUNCH("k_actor_tail_s3<4>", fl, by, k_actor_tail_s3<4>, dim3(nb + nb + nb2), dim3(64), t, tn[0], tn[1], nb, nb);
+        else LAUNCH("k_actor_tail3", fl, by, k_actor_tail3, dim3(nb + nb + nb2), dim3(256), t, tn[0], tn[1], nb, nb);
+      }
     }
     AlphaArgs al{};
     al.logp = e->logp_al; al.B = B; al.targ_ent = -(float)e->a; al.autotune = c.autotune; al.la = e->la; al.ctl = e->ctl;
@@ -917,10 +972,14 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 }
 
 // orchestrator.py:337-352 as one sequence
-static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak, bool next_in_same_graph = false) {
+// slot / pre_sampled / ahead: the pipelined form of a period graph (period_is_pipelined): iteration i of the period trains on batch
+// slot i; the first one (with the actor updates) also runs the sampling + next-action passes of the `ahead` iterations behind it,
+// which are then `pre_sampled`.
+static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak, bool next_in_same_graph = false,
+                        int slot = 0, bool pre_sampled = false, int ahead = 0) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   e->node_role = "sample";
-  if (!opening_trunk_gathers(e)) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
+  if (!pre_sampled && !opening_trunk_gathers(e)) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
   // SAC: critic targets are lerped towards the freshly stepped critics inside the Adam kernel (same element,
   // same order as agent.py:328 after :236); TD3 also needs the actor target, done after the actor updates.
   // Target updates (agents/agent.py:320-331) are folded into the kernels that apply the optimiser steps: the critic targets are
@@ -930,7 +989,7 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
   // few extra blocks of the critics' weight-gradient launch.
   bool policy_done = false, actor_targ_done = false;
   const bool actor_targ = do_polyak && td3;
-  RCCHK(enqueue_update_qnets(e, s, true, do_polyak ? e->Tc : nullptr, do_actor, &policy_done, actor_targ && !do_actor, &actor_targ_done));
+  RCCHK(enqueue_update_qnets(e, s, true, do_polyak ? e->Tc : nullptr, do_actor, &policy_done, actor_targ && !do_actor, &actor_targ_done, slot, pre_sampled));
   if (do_actor) {
     const int n = e->cfg.actor_update_delay;
     const bool can_merge = !td3 && e->cfg.autotune;
@@ -939,8 +998,8 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
       float* pt = nullptr;
       if (actor_targ && last) { pt = e->Ta; actor_targ_done = true; }
       // the last temperature step can wait for the next iteration's opening trunk launch when that launch can carry it
-      const bool defer = last && next_in_same_graph && !td3 && opening_trunk_carries_alpha(e);
-      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer));
+      const bool defer = last && next_in_same_graph && !td3 && (ahead > 0 || opening_trunk_carries_alpha(e));
+      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer, last ? ahead : 0));
     }
   }
   if (actor_targ && !actor_targ_done) RCCHK(enqueue_polyak(e, s, false, true));
@@ -1094,7 +1153,13 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
     RCCHK(dalloc(e, &e->eps[s], std::max<size_t>(B, e->maxn) * e->a));
   RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_xh1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_rs1, B));
   RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_xh2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_rs2, B));
-  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu)); RCCHK(dalloc(e, &e->a_z2n, BH));
+  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu)); RCCHK(dalloc(e, &e->a_z2n, BH)); RCCHK(dalloc(e, &e->a_z2m, BH));
+  e->bs[0] = {e->X, e->Xn, e->rew, e->done, e->logp_n, e->eps[SACTD3_SITE_CRITIC], e->idx};
+  for (int k = 1; k < 3; ++k) {
+    sactd3_engine::BatchSlot& S = e->bs[k];
+    RCCHK(dalloc(e, &S.X, B * e->ldc)); RCCHK(dalloc(e, &S.Xn, B * e->ldc)); RCCHK(dalloc(e, &S.rew, B)); RCCHK(dalloc(e, &S.done, B));
+    RCCHK(dalloc(e, &S.logp_n, B)); RCCHK(dalloc(e, &S.eps_c, std::max<size_t>(B, e->maxn) * e->a)); RCCHK(dalloc(e, &S.idx, B));
+  }
   RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
   RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_xh1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_rs1, 2 * B));
   RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));
@@ -1353,6 +1418,7 @@ int sactd3_rb_sample(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "rb_sample: buffer is empty");
+  e->cur_slot = 0;
   RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, e->stream, &e->ctl->sample_ctr, (int*)nullptr);
   HIPCHK(hipGetLastError());
@@ -1370,6 +1436,7 @@ int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->idx, h.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  e->cur_slot = 0;
   RCCHK(set_flag(e, &e->ctl->inject_idx, 1));
   RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
   return set_flag(e, &e->ctl->inject_idx, 0);
@@ -1385,6 +1452,7 @@ int sactd3_load_batch(sactd3_engine* e, const float* obs, const float* act, cons
     pack_record(e, e->h_batch + (size_t)i * e->rec_f, obs + (size_t)i * e->o, act + (size_t)i * e->a, rew[i], nobs + (size_t)i * e->o, dones[i]);
     h[i] = i;
   }
+  e->cur_slot = 0;
   HIPCHK(hipMemcpy(e->stage_dev, e->h_batch, sizeof(float) * (size_t)n * e->rec_f, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->idx, h.data(), sizeof(int) * n, hipMemcpyHostToDevice));
   RCCHK(set_flag(e, &e->ctl->inject_idx, 1));
@@ -1399,11 +1467,12 @@ int sactd3_read_batch(sactd3_engine* e, float* obs, float* act, float* rew, floa
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<float> hx((size_t)B * e->ldc), hn((size_t)B * e->ldc), hr(B), hd(B);
   std::vector<int> hi(B);
-  HIPCHK(hipMemcpy(hx.data(), e->X, sizeof(float) * hx.size(), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hn.data(), e->Xn, sizeof(float) * hn.size(), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hr.data(), e->rew, sizeof(float) * B, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hd.data(), e->done, sizeof(float) * B, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hi.data(), e->idx, sizeof(int) * B, hipMemcpyDeviceToHost));
+  const sactd3_engine::BatchSlot& S = e->bs[e->cur_slot];      // the slot of the most recent iteration
+  HIPCHK(hipMemcpy(hx.data(), S.X, sizeof(float) * hx.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hn.data(), S.Xn, sizeof(float) * hn.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hr.data(), S.rew, sizeof(float) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hd.data(), S.done, sizeof(float) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hi.data(), S.idx, sizeof(int) * B, hipMemcpyDeviceToHost));
   for (int b = 0; b < B; ++b) {
     if (obs) memcpy(obs + (size_t)b * e->o, hx.data() + (size_t)b * e->ldc, sizeof(float) * e->o);
     if (act) memcpy(act + (size_t)b * e->a, hx.data() + (size_t)b * e->ldc + e->o, sizeof(float) * e->a);
@@ -1435,6 +1504,8 @@ int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
   if (n < 1 || n > std::max(e->B, e->maxn)) return e->fail(SACTD3_EINVAL, "set_noise: too many rows");
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->eps[site], eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
+  if (site == SACTD3_SITE_CRITIC)      // (every batch slot: injected draws are "sticky until cleared", whichever slot an iteration trains on)
+    for (int k = 1; k < 3; ++k) HIPCHK(hipMemcpy(e->bs[k].eps_c, eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
   const int one = 1;
   HIPCHK(hipMemcpy(&e->ctl->inject_eps[site], &one, sizeof(int), hipMemcpyHostToDevice));
   return 0;
@@ -1452,7 +1523,8 @@ int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
   if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES || n < 1 || n > std::max(e->B, e->maxn)) return SACTD3_EINVAL;
   USE_DEVICE(e);
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(eps, e->eps[site], sizeof(float) * (size_t)n * e->a, hipMemcpyDeviceToHost));
+  const float* src = site == SACTD3_SITE_CRITIC ? e->bs[e->cur_slot].eps_c : e->eps[site];
+  HIPCHK(hipMemcpy(eps, src, sizeof(float) * (size_t)n * e->a, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1460,6 +1532,7 @@ int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
 int sactd3_update_qnets(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  e->cur_slot = 0;
   return run_graph(e, G_Q, [&](hipStream_t s) { return enqueue_update_qnets(e, s, false, nullptr); });
 }
 int sactd3_update_actor(sactd3_engine* e) {
@@ -1484,6 +1557,23 @@ int sactd3_step(sactd3_engine* e, int do_actor) {
   const int which = G_STEP00 + (act ? 2 : 0) + (polyak ? 1 : 0);
   RCCHK(run_graph(e, which, [&](hipStream_t s) { return enqueue_step(e, s, act, polyak); }));
   e->qnet_updates = updates;
+  e->cur_slot = 0;
+  return 0;
+}
+
+// Is the period graph built in its pipelined form (see BatchSlot)?  SAC with autotune (the last actor update ends with a trunk + tail
+// pair through the final actor: the temperature draw), one or two critic-only iterations behind it, and an opening trunk that reads
+// ring rows itself (narrow observations below the large-batch threshold, wide ones at large batch).
+static bool period_is_pipelined(const sactd3_engine* e) {
+  const sactd3_config& c = e->cfg;
+  return !c.prefer_td3_over_sac && c.autotune && c.actor_update_delay >= 1 && c.actor_update_delay <= 2 && opening_trunk_gathers(e);
+}
+static int enqueue_period(sactd3_engine* e, hipStream_t s) {
+  const int n = e->cfg.actor_update_delay + 1;
+  const bool pipe = period_is_pipelined(e);
+  for (int i = 0; i < n; ++i)
+    RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n, pipe ? i : 0, pipe && i > 0, pipe && i == 0 ? n - 1 : 0));
+  if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
   return 0;
 }
 
@@ -1498,12 +1588,9 @@ int sactd3_step_period(sactd3_engine* e) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   if (!td3 && e->cfg.crit_targ_update_freq != 1) return e->fail(SACTD3_ESTATE, "step_period: needs crit_targ_update_freq == 1");
   const int n = e->cfg.actor_update_delay + 1;
-  RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) {
-    for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n));
-    if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
-    return 0;
-  }));
+  RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s); }));
   e->qnet_updates += n;
+  e->cur_slot = period_is_pipelined(e) ? n - 1 : 0;
   return 0;
 }
 
@@ -1520,12 +1607,7 @@ int sactd3_instantiate_graphs(sactd3_engine* e) {
       RCCHK(run_graph(e, G_STEP00 + (a ? 2 : 0) + (py ? 1 : 0), [&](hipStream_t s) { return enqueue_step(e, s, a, py); }, false));
     }
   if (same_branch && e->cfg.actor_update_delay > 0) {
-    const int n = e->cfg.actor_update_delay + 1;
-    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) {
-      for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0, true, i + 1 < n));
-      if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
-      return 0;
-    }, false));
+    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s); }, false));
   }
   return 0;
 }
@@ -1615,9 +1697,10 @@ int sactd3_sync(sactd3_engine* e) {
 struct DbgEntry { const char* name; const float* ptr; int64_t n; };
 static std::vector<DbgEntry> dbg_table(sactd3_engine* e) {
   const int64_t B = e->B, BH = B * HID;
+  const sactd3_engine::BatchSlot& S = e->bs[e->cur_slot];
   return {
-      {"X", e->X, B * e->ldc}, {"Xn", e->Xn, B * e->ldc}, {"Xp", e->Xp, B * e->ldc}, {"rew", e->rew, B}, {"done", e->done, B},
-      {"logp_next", e->logp_n, B}, {"logp_pi", e->logp_pi, B}, {"logp_alpha", e->logp_al, B},
+      {"X", S.X, B * e->ldc}, {"Xn", S.Xn, B * e->ldc}, {"Xp", e->Xp, B * e->ldc}, {"rew", S.rew, B}, {"done", S.done, B},
+      {"logp_next", S.logp_n, B}, {"logp_pi", e->logp_pi, B}, {"logp_alpha", e->logp_al, B},
       {"a_xh1", e->a_xh1, BH}, {"a_h1", e->a_h1, BH}, {"a_z2", e->a_z2, BH}, {"a_h2", e->a_h2, BH}, {"a_du", e->a_du, B * e->ldu},
       {"a_dz2", e->a_dz2, BH}, {"a_dh1", e->a_dh1, BH}, {"a_dz1", e->a_dz1, BH},
       {"c_xh1", e->c_xh1, 2 * BH}, {"c_h1", e->c_h1, 2 * BH}, {"c_z2", e->c_z2, 2 * BH}, {"c_dz2", e->c_dz2, 2 * BH},
@@ -1705,8 +1788,9 @@ int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, 
   USE_DEVICE(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "time_nodes: buffer is empty");
   const bool act = do_actor != 0 && e->cfg.actor_update_delay > 0;
+  const bool period = do_actor == 2 && e->cfg.actor_update_delay > 0 && (e->cfg.prefer_td3_over_sac || e->cfg.crit_targ_update_freq == 1);
   std::vector<NodeInfo> log;
-  auto seq = [&]() -> int { e->node_seq = 0; return enqueue_step(e, e->stream, act, true); };
+  auto seq = [&]() -> int { e->node_seq = 0; return period ? enqueue_period(e, e->stream) : enqueue_step(e, e->stream, act, true); };
   auto done = [&](int rc) { e->node_only = -1; e->node_log = nullptr; e->node_seq = 0; e->node_role = ""; return rc; };
   e->node_log = &log; e->node_only = 1 << 30;               // list only, launch nothing
   int rc = seq();

@@ -301,6 +301,7 @@ struct GatherArgs {
   int B; int len_override;                // len_override >= 0: use it instead of ctl->rb_len (staged batches)
   unsigned rec4_magic;                    // ceil(2^32 / rec4) when B * rec4 * rec4 < 2^32, else 0
   int cpb;                                // chunks per thread = ceil(B * rec4 / (256 * blocks of the launch)), <= GATHER_CPT
+  int ctr_add;                            // the draw uses stream counter sample_ctr + ctr_add (a LATER iteration's sample, gathered ahead)
 };
 
 #ifndef GATHER_CPT
@@ -312,7 +313,7 @@ struct GatherArgs {
 __device__ __forceinline__ void gather_body(const GatherArgs& p, unsigned block) {
   __shared__ int ids_s[GATHER_CPT * 256 + 2];
   // one batch of requests for the sampling state (a field read behind a branch on another field is a second round trip)
-  const int inject = p.ctl->inject_idx, rb_len = p.ctl->rb_len, ctr = p.ctl->sample_ctr;
+  const int inject = p.ctl->inject_idx, rb_len = p.ctl->rb_len, ctr = p.ctl->sample_ctr + p.ctr_add;
   const unsigned long long seed = p.ctl->seed;
   const int len = p.len_override >= 0 ? p.len_override : rb_len;
   const unsigned total = (unsigned)p.B * (unsigned)p.rec4;             // host guarantees B * rec4 < 2^31
@@ -419,9 +420,10 @@ struct AlphaArgs {
   DevCtl* ctl; float lr, b1, b2, eps;
   int* tick;
 };
-// (a device function: also runs as one extra block of the next update's critic-trunk launch, see NtArgs::al)
+// (a device function: also runs as one extra block of the next update's critic-trunk launch, see NtArgs::al; in a block of more
+//  than 256 threads only the first 256 take part, so the sum is partitioned -- and rounds -- exactly as in a 256-thread block)
 __device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
-  __shared__ float red[4];
+  __shared__ float red[8];
   // the lead thread's state is requested together with the log-probs: fetched one after the other behind the
   // reduction it would be four dependent round trips in a kernel that does nothing else
   const bool lead = threadIdx.x == 0;
@@ -432,10 +434,10 @@ __device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
     if (a.tick) tk = *a.tick;
   }
   float s = 0.f;
-  if (a.autotune)
+  if (a.autotune && threadIdx.x < 256)
     for (int i = threadIdx.x; i < a.B; i += 256) s += -a.logp[i] - a.targ_ent;
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) & 7] = s;
   __syncthreads();
   if (lead) {
     if (a.autotune) {
@@ -461,10 +463,13 @@ struct NtGrp {               // one group of nets sharing an input and a paramet
   const float* P;                           // parameter arena of the group's first net; net stride p_ns
   float* Y;                                 // output, net stride y_ns
   float* xh_out; float* h_out; float* rstd_out;   // optional stores of the prologue rows by the column-tile-0 blocks
-  int ring_off;                             // ring_rows: float offset of this group's input field inside a replay record
+  // ring != 0: the input rows of this group are read straight from the replay ring -- row m = the record drawn for batch row m with
+  // stream counter sample_ctr + sctr_add (0: this iteration's sample; > 0: a later iteration's, whose next-action pass runs ahead),
+  // field at float offset ring_off; ring_idx = where the (injected) indices of that sample live
+  int ring; int ring_off; int sctr_add; const int* ring_idx;
 };
 struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = one 16 x 16 output tile, K split over the 4 waves
-  NtGrp g[2]; int npg;                      // blockIdx.z = grp * npg + net-in-group
+  NtGrp g[3]; int npg;                      // blockIdx.z = grp * npg + net-in-group
   int ld_in; long in_ns;
   int oW, ldw, oBias, oG, oBe; long p_ns;   // offsets inside a net's parameter block: W [N][ldw], bias (-1: none), LN affine of the A rows
   int ldy; long y_ns;
@@ -474,10 +479,10 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int* tick0; int* tick1;                   // optional counters bumped by (block 0, thread 0, net 0)
   float* adam_out; double* adam_pw; float lr, b1, b2;   // with tick0: publish this step's Adam scalars
   unsigned w1_magic;                        // ceil(2^32 / ldw1) for the W1 parking index arithmetic
-  // Fused replay sampling (first kernel of a fused iteration, FUSE1 only): the x rows are read straight from the replay
-  // ring (row = this sample's index, field offset ring_off floats) and `gblocks` extra blocks at the end of the grid do
-  // the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.
-  int ring_rows; int nt_blocks; int gblocks; GatherArgs ga;
+  // Fused replay sampling: groups with NtGrp::ring read their rows straight from the replay ring, and `gblocks` extra blocks at the
+  // end of the grid do the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.  Up to two
+  // gathers ride (gb_each blocks each: the samples of the two critic-only iterations of a period, into their own batch slots).
+  int nt_blocks; int gblocks; int gb_each; GatherArgs ga[2];
   // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
   int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
   int xr;                                // XCD row-block groups of the tile placement (xcd_tile; unfused launches), 0 = row-major numbering
@@ -486,7 +491,7 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
   // ... and the noise draws of the actor tail that follows this launch (see NoiseJob): nz_n jobs, nz[i].blocks blocks each
-  int nz_n; NoiseJob nz[2]; const DevCtl* nz_ctl;
+  int nz_n; NoiseJob nz[3]; const DevCtl* nz_ctl;
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -500,6 +505,17 @@ __device__ __forceinline__ f32x4 splitk_reduce(float* red /*[4][64][4]*/, f32x4 
     o[2] = (a.z + b.z) + (c.z + d.z); o[3] = (a.w + b.w) + (c.w + d.w);
   }
   return o;
+}
+
+// riding block x (behind the gather blocks) of a trunk launch: the pending temperature step, then the noise jobs
+__device__ __forceinline__ void riding_body(const NtArgs& p, int x) {
+  if (x < p.alpha_block) { alpha_body(p.al); return; }
+  x -= p.alpha_block;
+  if (x < p.nz[0].blocks) { noise_body(p.nz[0], p.nz_ctl, x); return; }
+  x -= p.nz[0].blocks;
+  if (p.nz_n > 1 && x < p.nz[1].blocks) { noise_body(p.nz[1], p.nz_ctl, x); return; }
+  x -= p.nz[1].blocks;
+  if (p.nz_n > 2) noise_body(p.nz[2], p.nz_ctl, x);
 }
 
 // PRO: 0 none, 1 LayerNorm+ReLU, 2 ReLU.  FUSE1: the A rows are produced by a fused first layer.
@@ -521,11 +537,9 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
   if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
     const int x = (int)blockIdx.x - p.nt_blocks;
-    if (x < p.gblocks) gather_body(p.ga, x);
+    if (x < p.gblocks) { if (blockIdx.z == 0) { if (x < p.gb_each) gather_body(p.ga[0], x); else gather_body(p.ga[1], x - p.gb_each); } }
     else if (blockIdx.z != 0) { }
-    else if (x < p.gblocks + p.alpha_block) alpha_body(p.al);
-    else if (x < p.gblocks + p.alpha_block + p.nz[0].blocks) noise_body(p.nz[0], p.nz_ctl, x - p.gblocks - p.alpha_block);
-    else if (p.nz_n > 1) noise_body(p.nz[1], p.nz_ctl, x - p.gblocks - p.alpha_block - p.nz[0].blocks);
+    else riding_body(p, x - p.gblocks);
     return;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
@@ -559,12 +573,12 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       w1r[u] = ld4(Pn + p.oW1 + 4 * (long)f);
     }
     const float* xrow = G.in + ni * p.in_ns + (long)mrow * p.ld_in;
-    if (p.ring_rows) {                                       // this sample's record in the replay ring
-      const int inject = p.ga.ctl->inject_idx, rb_len = p.ga.ctl->rb_len, sctr = p.ga.ctl->sample_ctr;   // one batch of requests
-      const unsigned long long seed = p.ga.ctl->seed;
+    if (G.ring) {                                            // (block-uniform) this sample's record in the replay ring
+      const int inject = p.ga[0].ctl->inject_idx, rb_len = p.ga[0].ctl->rb_len, sctr = p.ga[0].ctl->sample_ctr + G.sctr_add;   // one batch of requests
+      const unsigned long long seed = p.ga[0].ctl->seed;
       int id = (int)philox_index(seed, (unsigned)sctr, (unsigned)mrow, (unsigned)max(rb_len, 1));
-      if (inject) id = p.ga.idx[mrow];
-      xrow = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + G.ring_off;
+      if (inject) id = G.ring_idx[mrow];
+      xrow = reinterpret_cast<const float*>(p.ga[0].ring) + (long)id * (4 * p.ga[0].rec4) + G.ring_off;
     }
 #pragma unroll
     for (int c1 = 0; c1 < C1; ++c1) {
@@ -793,8 +807,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   const int r = lane & 15, kq = lane >> 4;
   // (256-thread instances) the replay gather into the batch slot as extra blocks behind the tile blocks, as in k_nt: the tile
   // blocks read their rows straight from the ring (ring_rows below), so nothing in this launch waits for the batch slot
-  const int tile_blocks = p.gblocks ? p.nt_blocks : (int)gridDim.x;
-  if (NTH == 256 && p.gblocks && (int)blockIdx.x >= tile_blocks) { gather_body(p.ga, blockIdx.x - tile_blocks); return; }
+  const int tile_blocks = (p.gblocks || p.alpha_block) ? p.nt_blocks : (int)gridDim.x;
+  if ((int)blockIdx.x >= tile_blocks) {           // (block-uniform) riding blocks: replay gathers (256-thread instances), a pending temperature step
+    const int x = (int)blockIdx.x - tile_blocks;
+    if (NTH == 256 && x < p.gblocks) { if (x < p.gb_each) gather_body(p.ga[0], x); else gather_body(p.ga[1], x - p.gb_each); }
+    else if (x >= p.gblocks && p.alpha_block) alpha_body(p.al);
+    return;
+  }
   if (blockIdx.x == 0 && t == 0) {
     if (p.tick0 || p.tick1) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
   }
@@ -816,19 +835,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   const float* ap[RA]; const float* wp[RW];
 #pragma unroll
   for (int u = 0; u < RA; ++u) ap[u] = A + (long)min(m0 + sr0 + SR * u, p.M - 1) * p.ld_in;
-  if (p.ring_rows) {                              // (uniform) row m = the sampled record's field: same draw as gather_body's
-    const int inject = p.ga.ctl->inject_idx, rb_len = p.ga.ctl->rb_len, sctr = p.ga.ctl->sample_ctr;   // one batch of requests
-    const unsigned long long seed = p.ga.ctl->seed;
+  if (G.ring) {                                   // (block-uniform) row m = the sampled record's field: same draw as gather_body's
+    const int inject = p.ga[0].ctl->inject_idx, rb_len = p.ga[0].ctl->rb_len, sctr = p.ga[0].ctl->sample_ctr + G.sctr_add;   // one batch of requests
+    const unsigned long long seed = p.ga[0].ctl->seed;
     int inj_id[RA];                                 // injected indices: requested with the control words, used only in injected mode
 #pragma unroll                                      // (a load behind `if (inject)` would be a second dependent round trip)
-    for (int u = 0; u < RA; ++u) inj_id[u] = p.ga.idx[min(m0 + sr0 + SR * u, p.M - 1)];
+    for (int u = 0; u < RA; ++u) inj_id[u] = G.ring_idx[min(m0 + sr0 + SR * u, p.M - 1)];
     __builtin_amdgcn_sched_barrier(0);              // all of the above are in flight before the first of them is waited for
 #pragma unroll
     for (int u = 0; u < RA; ++u) {
       const int m = min(m0 + sr0 + SR * u, p.M - 1);
       const int drawn = (int)philox_index(seed, (unsigned)sctr, (unsigned)m, (unsigned)max(rb_len, 1));
       const int id = inject ? min(max(inj_id[u], 0), max(rb_len, 1) - 1) : drawn;
-      ap[u] = reinterpret_cast<const float*>(p.ga.ring) + (long)id * (4 * p.ga.rec4) + G.ring_off;
+      ap[u] = reinterpret_cast<const float*>(p.ga[0].ring) + (long)id * (4 * p.ga[0].rec4) + G.ring_off;
     }
   }
 #pragma unroll
@@ -922,10 +941,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64_ln(NtArgs p) {       // Y
   // (256-thread instance) riding blocks behind the tile blocks, as in k_nt: a pending temperature step, the next tail's N(0,1) draws
   const int tile_blocks = (p.alpha_block || p.nz_n) ? p.nt_blocks : (int)gridDim.x;
   if (NTH == 256 && (int)blockIdx.x >= tile_blocks) {
-    const int x = (int)blockIdx.x - tile_blocks;
-    if (x < p.alpha_block) alpha_body(p.al);
-    else if (x < p.alpha_block + p.nz[0].blocks) noise_body(p.nz[0], p.nz_ctl, x - p.alpha_block);
-    else if (p.nz_n > 1) noise_body(p.nz[1], p.nz_ctl, x - p.alpha_block - p.nz[0].blocks);
+    riding_body(p, (int)blockIdx.x - tile_blocks);
     return;
   }
   const int tiles_n = (p.N + TN - 1) / TN, tiles = tiles_n * ((p.M + TM - 1) / TM);
@@ -1707,7 +1723,7 @@ struct ActorTail {
   int a4;
   float td3_std, td3_c, noise_std;
   int ctr_add;                           // the primary draw uses stream counter *ctr + ctr_add
-  int* tick;                             // optional counter bumped by (block 0, thread 0)
+  int* tick; int tick_add;               // optional counter advanced by 1 + tick_add by (block 0, thread 0)
   // SAC, dual mode: a SECOND, gradient-free draw through the same head outputs (the temperature step's fresh sample,
   // agents/agent.py:297-299) sharing this kernel with the next actor update's sample: only its log-prob is kept
   int dual; int site_buf2; unsigned site_code2; float* eps2; float* logp2;
@@ -1933,7 +1949,7 @@ __device__ __forceinline__ void actor_tail_body(const ActorTail& p, int block) {
     lp2 = row16_sum(lp2);
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
-  if (ticker) *p.tick = tick_v + 1;
+  if (ticker) *p.tick = tick_v + 1 + p.tick_add;
   if (p.done_flag) {                             // (uniform)
     __threadfence_system();
     __syncthreads();
@@ -1946,6 +1962,12 @@ __global__ __launch_bounds__(256) void k_actor_tail(ActorTail p) { actor_tail_bo
 __global__ __launch_bounds__(256) void k_actor_tail2(ActorTail a, ActorTail b, int nb_a) {
   if ((int)blockIdx.x < nb_a) actor_tail_body(a, blockIdx.x);
   else actor_tail_body(b, blockIdx.x - nb_a);
+}
+// ... three (a pipelined period: the last actor update's temperature draw + the next-action passes of the two critic-only iterations)
+__global__ __launch_bounds__(256) void k_actor_tail3(ActorTail a, ActorTail b, ActorTail c, int nb_a, int nb_b) {
+  if ((int)blockIdx.x < nb_a) actor_tail_body(a, blockIdx.x);
+  else if ((int)blockIdx.x < nb_a + nb_b) actor_tail_body(b, blockIdx.x - nb_a);
+  else actor_tail_body(c, blockIdx.x - nb_a - nb_b);
 }
 
 // Narrow heads (nh <= 8: Hopper's SAC head 2 x 3, HalfCheetah's TD3 head 6 ...).  The general kernel above spends two block
@@ -2085,7 +2107,7 @@ __device__ __forceinline__ void actor_tail_s_body(const ActorTail& p, int block)
     lp2 = row16_sum(lp2);
     if (sub == 0 && valid) p.logp2[b] = lp2;
   }
-  if (ticker) *p.tick = tick_v + 1;
+  if (ticker) *p.tick = tick_v + 1 + p.tick_add;
   if (p.done_flag) {                             // (uniform; RPB == 4: the block is one wave)
     __threadfence_system();
     if (RPB > 4) __syncthreads();
@@ -2100,6 +2122,12 @@ template <int RPB>
 __global__ __launch_bounds__(16 * RPB) void k_actor_tail_s2(ActorTail a, ActorTail b, int nb_a) {
   if ((int)blockIdx.x < nb_a) actor_tail_s_body<RPB>(a, blockIdx.x);
   else actor_tail_s_body<RPB>(b, blockIdx.x - nb_a);
+}
+template <int RPB>
+__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s3(ActorTail a, ActorTail b, ActorTail c, int nb_a, int nb_b) {
+  if ((int)blockIdx.x < nb_a) actor_tail_s_body<RPB>(a, blockIdx.x);
+  else if ((int)blockIdx.x < nb_a + nb_b) actor_tail_s_body<RPB>(b, blockIdx.x - nb_a);
+  else actor_tail_s_body<RPB>(c, blockIdx.x - nb_a - nb_b);
 }
 
 struct CriticTail {

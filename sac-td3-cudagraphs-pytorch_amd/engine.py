@@ -327,13 +327,14 @@ class Engine:
         self._ck(self.lib.sactd3_time_kernel(self._h, name.encode(), iters, C.byref(us)))
         return float(us.value)
 
-    def time_nodes(self, do_actor: bool, iters: int = 200):
-        """[{name, us, flops, bytes}] for every kernel node of one fused iteration (consumes the learner's state)."""
+    def time_nodes(self, which, iters: int = 200):
+        """[{name, us, flops, bytes, threads}] for every kernel node of: 0 / False a critic-only fused iteration, 1 / True one with
+        the actor updates, 2 a whole period of the schedule as sactd3_step_period captures it (consumes the learner's state)."""
         cap = 128
         us, fl, by, th = np.zeros(cap, np.float32), np.zeros(cap, np.float64), np.zeros(cap, np.float64), np.zeros(cap, np.int64)
         names = C.create_string_buffer(cap * 128)
         dp = C.POINTER(C.c_double)
-        n = self._ck(self.lib.sactd3_time_nodes(self._h, int(bool(do_actor)), iters, cap, names, len(names), _fp(us),
+        n = self._ck(self.lib.sactd3_time_nodes(self._h, int(which), iters, cap, names, len(names), _fp(us),
                                                 fl.ctypes.data_as(dp), by.ctypes.data_as(dp), th.ctypes.data_as(C.POINTER(C.c_int64))))
         labels = names.value.decode().split("\n")[:n]
         return [dict(name=labels[k], us=float(us[k]), flops=float(fl[k]), bytes=float(by[k]), threads=int(th[k])) for k in range(n)]

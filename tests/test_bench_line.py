@@ -101,7 +101,7 @@ def test_roofline_groups_sum_the_grids_of_one_kernel_instance():
     g1 = g0 + [mk("k_nn:actor/dh1", 3.5, 33.5e6, 1.5e6, 4096), mk("k_nn:actor/dq_da", 4.0, 8e6, 0.5e6, 1024), mk("k_nn:actor/dh1'", 3.5, 33.5e6, 1.5e6, 4096)]
     traffic = {("k_nn", 4096): dict(traffic=4e6, calls=30, source="f.csv"), ("k_nn", 1024): dict(traffic=1e6, calls=10, source="f.csv")}
     per_iter = (2 * sum(n["us"] for n in g0) + sum(n["us"] for n in g1)) / 3
-    by_name, by_grid = bench.roofline_groups(g0, g1, traffic, per_iter)
+    by_name, by_grid = bench.roofline_groups([(2.0 / 3.0, g0), (1.0 / 3.0, g1)], traffic, per_iter)
     nn = [r for r in by_name if r["kernel"] == "k_nn"][0]
     assert nn["grids"] == [1024, 4096] and abs(nn["launches_per_iteration"] - (1 + 3 / 3)) < 1e-9
     us = (2 * 3.0 + (3.0 + 3.5 + 4.0 + 3.5)) / 3
