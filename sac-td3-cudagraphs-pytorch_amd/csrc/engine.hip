@@ -74,7 +74,7 @@ static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst)
 }
 
 static const int BIG_BATCH = 1024;   // from here on the hidden layers run as 64 x 64-tiled GEMMs + a LayerNorm row kernel
-enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_PERIOD = 6, G_COUNT = 7 };
+enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_PERIOD = 6, G_PERIOD_B = 7, G_OPENING = 8, G_COUNT = 9 };
 static const int NSTAGE = 32;
 
 struct NodeInfo { std::string name; double flops; double bytes; long threads; };
@@ -109,12 +109,18 @@ struct sactd3_engine {
   float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
   float* a_z2n = nullptr;        // layer-2 output of the s' pass when the pi(s) pass shares its launch
-  float* a_z2m = nullptr;        // ... of a second s' pass that runs ahead (pipelined period, see BatchSlot)
-  // Batch slots.  Slot 0 is THE batch slot (X, Xn, rew, done, idx, logp_n, eps of the critic site above); a pipelined period graph
+  float* ah_z1[4] = {}; float* ah_z2[4] = {};   // layer outputs of the passes that run ahead (pipelined period, see BatchSlot)
+  // Batch slots.  Slot 0 is THE batch slot (X, Xn, rew, done, idx, logp_n, eps of the critic site above).  A pipelined period graph
   // (sactd3_step_period, SAC) samples and runs the next-action pass of its critic-only iterations AHEAD, inside the last actor
-  // update's launches -- the actor does not change in between -- into slots 1 and 2, which those iterations then train on.
-  struct BatchSlot { float *X, *Xn, *rew, *done, *logp_n, *eps_c; int* idx; } bs[3] = {};
+  // update's launches -- the actor does not change in between -- into slots 1 and 2, which those iterations then train on; and it
+  // does the same for the opening pair of the NEXT period's first iteration (next-action pass on s' and the first actor update's
+  // policy pass on s), whose slot alternates between 0 and 3 from one period to the next (the running period still reads its own).
+  struct BatchSlot { float *X, *Xn, *rew, *done, *logp_n, *eps_c; int* idx; } bs[4] = {};
   int cur_slot = 0;              // the slot the most recent iteration trained on (what read_batch / read_noise / debug_read report)
+  // chain_ready = v (0 / 1): the previous sactd3_step_period left the opening pair of the next period precomputed in slot (v ? 3 : 0)
+  // and nothing has touched the state it depends on since (parameters, ring length, counters, noise injection, the slots);
+  // -1: not so -- the next period starts with the opening graph.  Every state-changing ABI call resets it (CHAIN_BREAK).
+  int chain_ready = -1;
   float *c_z1 = nullptr, *c_xh1 = nullptr, *c_h1 = nullptr, *c_rs1 = nullptr, *c_z2 = nullptr, *c_dz2 = nullptr, *c_dh1 = nullptr, *c_dz1 = nullptr;
   float *t_z1 = nullptr, *t_z2 = nullptr, *q = nullptr, *qt = nullptr, *y = nullptr, *q_pi = nullptr, *dA = nullptr;
   float* s_h1 = nullptr;         // large-batch path: layer-1 activations of nets whose caller keeps no copy ([4][B][256])
@@ -157,6 +163,8 @@ struct sactd3_engine {
     if (_he != hipSuccess) return (e)->fail(SACTD3_EHIP, "hipSetDevice", _he);               \
     (void)hipGetLastError();   /* a stale error of an unrelated earlier call must not be blamed on this one */ \
   } while (0)
+// any call that changes what a precomputed opening pair depends on (see sactd3_engine::chain_ready)
+#define CHAIN_BREAK(e) do { (e)->chain_ready = -1; } while (0)
 #define RCCHK(call)                    \
   do {                                 \
     int _rc = (call);                  \
@@ -288,7 +296,8 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     // unfused launches read whole input rows: place the tiles so that an XCD pulls few rows and few weight columns (the fused
     // form's input rows are a few dozen bytes: it keeps one weight column tile per XCD, the row-major numbering)
     gg.xr = fuse1 ? 0 : pick_xr(e, (g.M + rb - 1) / rb, tiles_n / nt, 4.0 * g.M * g.K, 4.0 * g.N * g.K);
-    const int nzb = (gg.nz_n > 0 ? gg.nz[0].blocks : 0) + (gg.nz_n > 1 ? gg.nz[1].blocks : 0) + (gg.nz_n > 2 ? gg.nz[2].blocks : 0);
+    int nzb = 0;
+    for (int i = 0; i < gg.nz_n && i < 5; ++i) nzb += gg.nz[i].blocks;
     const dim3 grid((unsigned)(gg.nt_blocks + gg.gblocks + gg.alpha_block + nzb), 1, (unsigned)nets);
     char inst[64] = "k_nt";
     if (e->node_log) {
@@ -451,9 +460,9 @@ static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] 
 struct TrunkGrp { const float* x; const float* P; float* z1; float* z2; float* xh; float* h; float* rstd; int ring_off = 0;
                   bool ring = false; int sctr_add = 0; const int* ring_idx = nullptr; };
 struct TrunkTicks { int* tick0; int* tick1; float* adam_out; double* adam_pw; float lr;
-                    int ngather = 0; GatherArgs gather[2] = {};   // replay gathers into batch slots riding as extra blocks (launches with ring groups)
+                    int ngather = 0; GatherArgs gather[3] = {};   // replay gathers into batch slots riding as extra blocks (launches with ring groups)
                     const AlphaArgs* alpha = nullptr;      // alpha: a pending temperature step to carry as one extra block
-                    int nnoise = 0; NoiseJob noise[3] = {}; bool* noise_taken = nullptr;      // the following tail's draws (see NoiseJob)
+                    int nnoise = 0; NoiseJob noise[5] = {}; bool* noise_taken = nullptr;      // the following tails' draws (see NoiseJob)
                     int force_ks = 0;                      // keep the single-net launch's K split (bit-equal results across launch shapes)
                     bool no_tiled64 = false;               // keep the 32 x 32-tile launches (the ones that can read ring rows / carry gathers)
                     int* tick0b = nullptr; float* adam_out_b = nullptr; double* adam_pw_b = nullptr; float lr_b = 0.f; };   // a second step counter
@@ -470,8 +479,8 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   const bool big_path = M >= BIG_BATCH && M == e->B && ((M + 63) / 64) * (HID / 64) * nets >= (3 * e->num_cus) / 4 && !tk.no_tiled64;
   auto set_ring = [&](NtArgs& a) {   // which groups read their rows from the replay ring, and the gathers that ride along
     for (int i = 0; i < ngrp; ++i) { a.g[i].ring = grp[i].ring ? 1 : 0; a.g[i].ring_off = grp[i].ring_off; a.g[i].sctr_add = grp[i].sctr_add; a.g[i].ring_idx = grp[i].ring_idx; }
-    a.ga[0] = tk.ngather > 0 ? tk.gather[0] : gather_args(e, e->ring, -1);     // (ring groups take the ring / control block from ga[0])
-    if (tk.ngather > 1) a.ga[1] = tk.gather[1];
+    a.ga[0] = gather_args(e, e->ring, -1);                                     // (ring groups take the ring / control block from ga[0])
+    for (int i = 0; i < tk.ngather && i < 3; ++i) a.ga[i] = tk.gather[i];
     a.gb_each = tk.ngather > 0 ? (int)gather_blocks((long)e->B * e->rec4) : 0;
     a.gblocks = tk.ngather * a.gb_each;
   };
@@ -565,7 +574,8 @@ static int enqueue_trunk(sactd3_engine* e, hipStream_t s, int ldx, int K, int M,
   if (M >= BIG_BATCH && M == e->B && !(e->tune_rows4 & 256)) {   // large batch: the 32 x 32 LDS-tiled form with the LayerNorm prologue
     h.ln_pro = e->cfg.layer_norm ? 1 : 0;
     h.nt_blocks = ((M + 31) / 32) * (HID / 32) * nets;
-    const int nzb = (h.nz_n > 0 ? h.nz[0].blocks : 0) + (h.nz_n > 1 ? h.nz[1].blocks : 0) + (h.nz_n > 2 ? h.nz[2].blocks : 0);
+    int nzb = 0;
+    for (int i = 0; i < h.nz_n && i < 5; ++i) nzb += h.nz[i].blocks;
     double st = 0.0;
     for (int i = 0; i < ngrp; ++i) st += ((grp[i].xh ? 1.0 : 0.0) + (grp[i].h ? 1.0 : 0.0)) / ngrp;
     LAUNCH("k_nt64_ln<2,2,1>.layer2", 2.0 * nets * (double)M * HID * HID, 4.0 * nets * ((double)HID * (HID + 3) + (double)M * HID * (2.0 + st)),
@@ -657,7 +667,10 @@ static bool opening_trunk_carries_alpha(const sactd3_engine* e) {
 // `ahead`): the update starts at the twin-critic trunk, which then carries the step-counter tick and a deferred temperature step.
 static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_sample, float* fused_polyak_targ,
                                 bool with_policy = false, bool* policy_done = nullptr, bool actor_targ_rides = false, bool* actor_targ_done = nullptr,
-                                int slot = 0, bool pre_sampled = false) {
+                                int slot = 0, bool pre_sampled = false, int open_mode = 0) {
+  // open_mode (chained periods): 1 = ONLY the opening pair (trunk + tails incl. the first actor update's policy pass), without the
+  // step-counter / sample-counter ticks, then return -- the "opening graph"; 2 = (with pre_sampled) this is the period's first
+  // iteration whose opening pair was precomputed: the twin-critic trunk also makes those ticks (critics', actor's, sample counter)
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac;
   const long BH = (long)B * HID;
@@ -676,6 +689,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     TrunkGrp g[2] = {{S.Xn, Pact, wide_merge ? e->t_z1 : e->a_z1, merge_policy ? e->a_z2n : e->a_z2, nullptr, nullptr, nullptr, e->ldc},
                      {S.X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1, 0}};
     TrunkTicks tk{&e->ctl->t_q, (fused_sample && !in_kernel_gather) ? &e->ctl->sample_ctr : nullptr, e->ctl->adam_q, e->ctl->pw_q, c.qnets_lr};
+    if (open_mode == 1) { tk.tick0 = nullptr; tk.tick1 = nullptr; tk.adam_out = nullptr; tk.adam_pw = nullptr; }
     if (in_kernel_gather) {   // the trunk reads its rows from the ring itself; the gather into the batch slot rides along
       tk.ngather = 1; tk.gather[0] = gather_args(e, e->ring, -1, slot);
       for (auto& gg : g) { gg.ring = true; gg.ring_idx = S.idx; }
@@ -697,13 +711,13 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       // counter one ahead (the critic update's last kernel bumps it before the actor update would have read it)
       if (!td3) { tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, 1 + owed, B); tk.noise_taken = &eps_ready; }
       if (!wide_merge) tk.force_ks = 4;
-      tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
+      if (open_mode != 1) { tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr; }
     }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, merge_policy ? 2 : 1, 1, g, tk));
     ActorTail t = tail_args(e, merge_policy ? e->a_z2n : e->a_z2, Pact, B, mode, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
     t.eps = S.eps_c;
     t.eps_ready = eps_ready; t.ctr_add = owed;
-    if (in_kernel_gather) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
+    if (in_kernel_gather && open_mode != 1) t.tick = &e->ctl->sample_ctr;   // every reader of the index stream (the trunk kernel) is done
     if (merge_policy && tail_rows_per_block(t) == 4) {
       ActorTail t1 = tail_args(e, e->a_z2, e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
       t1.obs_src = S.X; t1.lds = e->ldc; t1.ctr_add = 1 + owed; t1.eps_ready = eps_ready;     // Xp = [s | pi(s)]
@@ -719,6 +733,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
              k_actor_tail2, dim3(2 * nb), dim3(256), t, t1, nb);
       if (policy_done) *policy_done = true;
     } else RCCHK(launch_tail(e, s, t));
+    if (open_mode == 1) return (merge_policy && policy_done && *policy_done) ? 0 : e->fail(SACTD3_ESTATE, "opening graph: the policy pass did not merge");
   }
   {  // twin target critics on (s', a') and twin online critics on (s, a) in one launch (agent.py:208-210, 230-232).
      // (Measured: running the online pair on a fork/join side branch of the graph instead costs +30 us per replay on
@@ -730,6 +745,10 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     if (pre_sampled) {   // this launch opens the update: the critics' step counter + Adam scalars, and a temperature step deferred from the
                          // period's first iteration (its tick of the noise counter is made up by this update's last kernel)
       tk.tick0 = &e->ctl->t_q; tk.adam_out = e->ctl->adam_q; tk.adam_pw = e->ctl->pw_q; tk.lr = c.qnets_lr;
+      if (open_mode == 2) {   // ... the ticks the precomputed opening pair left undone: the sample counter and the actor's step counter
+        tk.tick1 = &e->ctl->sample_ctr;
+        tk.tick0b = &e->ctl->t_a; tk.adam_out_b = e->ctl->adam_a; tk.adam_pw_b = e->ctl->pw_a; tk.lr_b = c.actor_lr;
+      }
       if (e->alpha_pending && e->alpha_tick_owed) { tk.alpha = &e->pending_alpha; e->alpha_pending = false; e->alpha_tick_owed = false; ctr_owed = 1; }
     }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, tk));
@@ -795,23 +814,26 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
 // next-action pass a' ~ pi(s') of the `ahead` critic-only iterations that follow, into batch slots 1 .. ahead: the actor does not
 // change any more before they run, so their passes ride in this update's last trunk / tail launches (the temperature draw's) as
 // extra groups -- those iterations then start at their twin-critic trunk (enqueue_update_qnets, pre_sampled).
+// chain_slot >= 0: ... and the opening pair of the NEXT period's first iteration into that batch slot (see BatchSlot, chain_ready).
+// slot: the batch slot this iteration trains on.
 static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool head_done = false, bool merge_next = false, float* polyak_targ = nullptr,
-                                bool defer_alpha = false, int ahead = 0) {
+                                bool defer_alpha = false, int ahead = 0, int chain_slot = -1, int slot = 0) {
   const sactd3_config& c = e->cfg;
   const int B = e->B, ln = c.layer_norm, td3 = c.prefer_td3_over_sac, nq = e->nq_actor;
   const long BH = (long)B * HID;
   const int sb_a = SACTD3_SITE_ACTOR0 + (j & 1), sb_l = SACTD3_SITE_ALPHA0 + (j & 1);
   const bool clip = c.clip_norm > 0.f;
+  const float* SX = e->bs[slot].X;          // the observations of the batch this iteration trains on
   const bool small_head = e->nh <= 8 && e->a <= 8 && !(e->tune_rows4 & 4);      // single-wave 4-row head backward (k_actor_head_bwd_s)
   e->node_role = (j & 1) ? "actor1/policy" : "actor0/policy";
   if (!head_done) {  // a_pi, logp = pi(s) with stores for the backward pass
-    const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
+    const TrunkGrp g{SX, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
     TrunkTicks tk{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr};
     bool eps_ready = false;
     if (!td3) { tk.nnoise = 1; tk.noise[0] = noise_job(e, sb_a, 16u, 0, B); tk.noise_taken = &eps_ready; }
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
     ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-    t.obs_src = e->X; t.lds = e->ldc;   // Xp = [s | pi(s)]
+    t.obs_src = SX; t.lds = e->ldc;   // Xp = [s | pi(s)]
     t.eps_ready = eps_ready;
     RCCHK(launch_tail(e, s, t));
   }
@@ -874,7 +896,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
     g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
     if (ln) { tn_fin(g.pr[1], 0, e->La.g2, small_head ? e->nblk4 : e->nblk); tn_fin(g.pr[1], 1, e->La.be2, small_head ? e->nblk4 : e->nblk); }
-    g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, e->X, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
+    g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, SX, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
     if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = clip ? nullptr : polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_a;
@@ -899,51 +921,75 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
       // the SAME freshly updated actor on the SAME observations: one trunk launch (with the next update's backward
       // stores and Adam tick) and one tail launch with two draws.  Streams: temperature (ctr, 32), policy (ctr + 1, 16),
       // exactly what the two separate launches would consume.
-      const TrunkGrp g{e->X, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
+      const TrunkGrp g{SX, e->Pa, e->a_z1, e->a_z2, e->a_xh1, e->a_h1, e->a_rs1};
       const int sb_a_next = SACTD3_SITE_ACTOR0 + ((j + 1) & 1);
       TrunkTicks tk{&e->ctl->t_a, nullptr, e->ctl->adam_a, e->ctl->pw_a, c.actor_lr};
       bool eps_ready = false;
       tk.nnoise = 2; tk.noise[0] = noise_job(e, sb_a_next, 16u, 1, B); tk.noise[1] = noise_job(e, sb_l, 32u, 0, B); tk.noise_taken = &eps_ready;
       RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1, 1, &g, tk));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 1, sb_a_next, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
-      t.obs_src = e->X; t.lds = e->ldc; t.ctr_add = 1;
+      t.obs_src = SX; t.lds = e->ldc; t.ctr_add = 1;
       t.dual = 1; t.site_buf2 = sb_l; t.site_code2 = 32u; t.eps2 = e->eps[sb_l]; t.logp2 = e->logp_al;
       t.eps_ready = eps_ready;
       RCCHK(launch_tail(e, s, t));
     } else if (c.autotune) {  // fresh draw through the already-updated actor (agent.py:297-299)
-      TrunkGrp g[3] = {{e->X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr}, {}, {}};
+      TrunkGrp g[5] = {{e->bs[slot].X, e->Pa, e->a_z1, e->a_z2, nullptr, nullptr, nullptr}, {}, {}, {}, {}};
       TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
       bool eps_ready = false;
       tk.nnoise = 1; tk.noise[0] = noise_job(e, sb_l, 32u, 0, B); tk.noise_taken = &eps_ready;
-      float* z2k[2] = {e->a_z2n, e->a_z2m};
+      ActorTail5 T{};
+      int ng = 1;
+      // The noise counter stands at N + (this update's index + 1) here (one tick by the critic update, one per finished temperature
+      // step), the sample counter already counts this iteration.  Iteration k of the period (k = 1 .. ahead): its sample is the
+      // one drawn with sample_ctr + (k - 1), its critic-site draws those of noise counter + k (the tick owed by this update's
+      // deferred temperature step, one per critic update in between) -- exactly what its own opening launches would have used.
       for (int k = 1; k <= ahead; ++k) {
-        // iteration k of the period: its sample is the one drawn with sample_ctr + (k - 1) (the counter already counts this
-        // iteration's), its critic-site draws those of noise counter + k (one tick by this iteration's deferred temperature step,
-        // one per critic update in between) -- exactly what that iteration's own opening launches would have used
         const sactd3_engine::BatchSlot& S = e->bs[k];
-        g[k] = TrunkGrp{S.Xn, e->Pa, e->t_z1 + (size_t)(k - 1) * BH, z2k[k - 1], nullptr, nullptr, nullptr, e->ldc};
-        g[k].ring = true; g[k].sctr_add = k - 1; g[k].ring_idx = S.idx;
+        g[ng] = TrunkGrp{S.Xn, e->Pa, e->ah_z1[k - 1], e->ah_z2[k - 1], nullptr, nullptr, nullptr, e->ldc};
+        g[ng].ring = true; g[ng].sctr_add = k - 1; g[ng].ring_idx = S.idx;
         tk.gather[tk.ngather++] = gather_args(e, e->ring, -1, k, k - 1);
         tk.noise[tk.nnoise] = noise_job(e, SACTD3_SITE_CRITIC, 0u, k, B); tk.noise[tk.nnoise++].eps = S.eps_c;
+        T.t[ng] = tail_args(e, e->ah_z2[k - 1], e->Pa, B, 0, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
+        T.t[ng].eps = S.eps_c; T.t[ng].ctr_add = k;
+        ++ng;
       }
-      if (ahead) { tk.force_ks = 4; tk.no_tiled64 = true; e->node_role = (j & 1) ? "actor1/alpha & next-action passes ahead" : "actor0/alpha & next-action passes ahead"; }
-      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, 1 + ahead, 1, g, tk));
+      // ... and the opening pair of the NEXT period's first iteration, into batch slot `chain_slot`: sample sample_ctr + ahead,
+      // critic-site draws of noise counter + ahead + 1 (where that period starts), policy draws (site 16) one further -- the values
+      // its own opening launches use (enqueue_update_qnets: merge_policy); the policy pass keeps its stores for the backward pass
+      if (chain_slot >= 0) {
+        const sactd3_engine::BatchSlot& S = e->bs[chain_slot];
+        g[ng] = TrunkGrp{S.Xn, e->Pa, e->ah_z1[2], e->ah_z2[2], nullptr, nullptr, nullptr, e->ldc};
+        g[ng].ring = true; g[ng].sctr_add = ahead; g[ng].ring_idx = S.idx;
+        g[ng + 1] = TrunkGrp{S.X, e->Pa, e->ah_z1[3], e->ah_z2[3], e->a_xh1, e->a_h1, e->a_rs1, 0};
+        g[ng + 1].ring = true; g[ng + 1].sctr_add = ahead; g[ng + 1].ring_idx = S.idx;
+        tk.gather[tk.ngather++] = gather_args(e, e->ring, -1, chain_slot, ahead);
+        tk.noise[tk.nnoise] = noise_job(e, SACTD3_SITE_CRITIC, 0u, ahead + 1, B); tk.noise[tk.nnoise++].eps = S.eps_c;
+        tk.noise[tk.nnoise++] = noise_job(e, SACTD3_SITE_ACTOR0, 16u, ahead + 2, B);
+        T.t[ng] = tail_args(e, e->ah_z2[2], e->Pa, B, 0, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
+        T.t[ng].eps = S.eps_c; T.t[ng].ctr_add = ahead + 1;
+        T.t[ng + 1] = tail_args(e, e->ah_z2[3], e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+        T.t[ng + 1].obs_src = S.X; T.t[ng + 1].lds = e->ldc; T.t[ng + 1].ctr_add = ahead + 2;      // Xp = [s | pi(s)] (the gather above has filled S.X)
+        ng += 2;
+      }
+      if (ng > 1) {
+        tk.force_ks = 4; tk.no_tiled64 = true;
+        e->node_role = chain_slot >= 0 ? "alpha & next-action passes ahead & next period's opening" : "alpha & next-action passes ahead";
+      }
+      RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, ng, 1, g, tk));
       ActorTail t = tail_args(e, e->a_z2, e->Pa, B, 0, 0, sb_l, 32u, e->act_scratch, e->a4, 0, e->logp_al);
       t.eps_ready = eps_ready;
-      if (!ahead) RCCHK(launch_tail(e, s, t));
+      if (ng == 1) RCCHK(launch_tail(e, s, t));
       else {
-        ActorTail tn[2];
-        for (int k = 1; k <= 2; ++k) {
-          const sactd3_engine::BatchSlot& S = e->bs[std::min(k, ahead)];
-          tn[k - 1] = tail_args(e, z2k[std::min(k, ahead) - 1], e->Pa, B, 0, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
-          tn[k - 1].eps = S.eps_c; tn[k - 1].eps_ready = eps_ready; tn[k - 1].ctr_add = std::min(k, ahead);
-        }
-        t.tick = &e->ctl->sample_ctr; t.tick_add = ahead - 1;      // every reader of the index streams (the trunk launch above) is done
-        const int rpb = tail_rows_per_block(t), nb = (B + rpb - 1) / rpb, nb2 = ahead > 1 ? nb : 0;
-        const double fl = 2.0 * (1 + ahead) * B * (double)HID * t.L.nh;
-        const double by = 4.0 * (1 + ahead) * ((double)B * HID + (double)t.L.nh * (HID + 1) + 2.0 * HID + (double)B * (3 * e->a + 2));
-        if (rpb == 4) LAUNCH("k_actor_tail_s3<4>", fl, by, k_actor_tail_s3<4>, dim3(nb + nb + nb2), dim3(64), t, tn[0], tn[1], nb, nb);
-        else LAUNCH("k_actor_tail3", fl, by, k_actor_tail3, dim3(nb + nb + nb2), dim3(256), t, tn[0], tn[1], nb, nb);
+        if (ahead) { t.tick = &e->ctl->sample_ctr; t.tick_add = ahead - 1; }      // every reader of the index streams (the trunk launch above) is done
+        T.t[0] = t;
+        for (int i = 1; i < ng; ++i) T.t[i].eps_ready = eps_ready;
+        for (int i = ng; i < 5; ++i) T.t[i] = T.t[0];                               // (never run: blocks exist for n tails only)
+        const int rpb = tail_rows_per_block(t);
+        T.nb = (B + rpb - 1) / rpb; T.n = ng;
+        const double fl = 2.0 * ng * B * (double)HID * t.L.nh;
+        const double by = 4.0 * ng * ((double)B * HID + (double)t.L.nh * (HID + 1) + 2.0 * HID + (double)B * (3 * e->a + 2)) + (chain_slot >= 0 ? 8.0 * (double)B * (HID + e->o) : 0.0);
+        if (rpb == 4) LAUNCH("k_actor_tail_s5<4>", fl, by, k_actor_tail_s5<4>, dim3(ng * T.nb), dim3(64), T);
+        else LAUNCH("k_actor_tail5", fl, by, k_actor_tail5, dim3(ng * T.nb), dim3(256), T);
       }
     }
     AlphaArgs al{};
@@ -975,8 +1021,10 @@ static int enqueue_polyak(sactd3_engine* e, hipStream_t s, bool critics, bool ac
 // slot / pre_sampled / ahead: the pipelined form of a period graph (period_is_pipelined): iteration i of the period trains on batch
 // slot i; the first one (with the actor updates) also runs the sampling + next-action passes of the `ahead` iterations behind it,
 // which are then `pre_sampled`.
+// chain_slot / policy_pre: ... and, chained periods, the opening pair of the next period's first iteration into batch slot chain_slot;
+// policy_pre = this iteration's own opening pair (sample, next-action pass, the first actor update's policy pass) is already there.
 static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_polyak, bool next_in_same_graph = false,
-                        int slot = 0, bool pre_sampled = false, int ahead = 0) {
+                        int slot = 0, bool pre_sampled = false, int ahead = 0, int chain_slot = -1, bool policy_pre = false) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   e->node_role = "sample";
   if (!pre_sampled && !opening_trunk_gathers(e)) RCCHK(enqueue_gather(e, s, e->ring, -1));   // otherwise the gather is inside the first trunk kernel
@@ -989,7 +1037,9 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
   // few extra blocks of the critics' weight-gradient launch.
   bool policy_done = false, actor_targ_done = false;
   const bool actor_targ = do_polyak && td3;
-  RCCHK(enqueue_update_qnets(e, s, true, do_polyak ? e->Tc : nullptr, do_actor, &policy_done, actor_targ && !do_actor, &actor_targ_done, slot, pre_sampled));
+  RCCHK(enqueue_update_qnets(e, s, true, do_polyak ? e->Tc : nullptr, do_actor, &policy_done, actor_targ && !do_actor, &actor_targ_done, slot, pre_sampled,
+                             policy_pre ? 2 : 0));
+  if (policy_pre) policy_done = true;
   if (do_actor) {
     const int n = e->cfg.actor_update_delay;
     const bool can_merge = !td3 && e->cfg.autotune;
@@ -999,7 +1049,7 @@ static int enqueue_step(sactd3_engine* e, hipStream_t s, bool do_actor, bool do_
       if (actor_targ && last) { pt = e->Ta; actor_targ_done = true; }
       // the last temperature step can wait for the next iteration's opening trunk launch when that launch can carry it
       const bool defer = last && next_in_same_graph && !td3 && (ahead > 0 || opening_trunk_carries_alpha(e));
-      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer, last ? ahead : 0));
+      RCCHK(enqueue_update_actor(e, s, j, j == 0 ? policy_done : can_merge, can_merge && !last, pt, defer, last ? ahead : 0, last ? chain_slot : -1, slot));
     }
   }
   if (actor_targ && !actor_targ_done) RCCHK(enqueue_polyak(e, s, false, true));
@@ -1153,9 +1203,10 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
     RCCHK(dalloc(e, &e->eps[s], std::max<size_t>(B, e->maxn) * e->a));
   RCCHK(dalloc(e, &e->a_z1, BH)); RCCHK(dalloc(e, &e->a_xh1, BH)); RCCHK(dalloc(e, &e->a_h1, BH)); RCCHK(dalloc(e, &e->a_rs1, B));
   RCCHK(dalloc(e, &e->a_z2, BH)); RCCHK(dalloc(e, &e->a_xh2, BH)); RCCHK(dalloc(e, &e->a_h2, BH)); RCCHK(dalloc(e, &e->a_rs2, B));
-  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu)); RCCHK(dalloc(e, &e->a_z2n, BH)); RCCHK(dalloc(e, &e->a_z2m, BH));
+  RCCHK(dalloc(e, &e->a_tg, B * 4 * e->a4)); RCCHK(dalloc(e, &e->a_du, B * e->ldu)); RCCHK(dalloc(e, &e->a_z2n, BH));
   e->bs[0] = {e->X, e->Xn, e->rew, e->done, e->logp_n, e->eps[SACTD3_SITE_CRITIC], e->idx};
-  for (int k = 1; k < 3; ++k) {
+  for (int k = 0; k < 4; ++k) { RCCHK(dalloc(e, &e->ah_z1[k], BH)); RCCHK(dalloc(e, &e->ah_z2[k], BH)); }
+  for (int k = 1; k < 4; ++k) {
     sactd3_engine::BatchSlot& S = e->bs[k];
     RCCHK(dalloc(e, &S.X, B * e->ldc)); RCCHK(dalloc(e, &S.Xn, B * e->ldc)); RCCHK(dalloc(e, &S.rew, B)); RCCHK(dalloc(e, &S.done, B));
     RCCHK(dalloc(e, &S.logp_n, B)); RCCHK(dalloc(e, &S.eps_c, std::max<size_t>(B, e->maxn) * e->a)); RCCHK(dalloc(e, &S.idx, B));
@@ -1280,6 +1331,7 @@ int sactd3_get_params(sactd3_engine* e, int which, float* dst) {
 int sactd3_set_params(sactd3_engine* e, int which, const float* src) {
   if (!e || !src) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (which == SACTD3_LOG_ALPHA) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->la, src, sizeof(float), hipMemcpyHostToDevice));
@@ -1316,6 +1368,7 @@ int sactd3_get_adam_state(sactd3_engine* e, int which, float* m, float* v, int64
 int sactd3_set_adam_state(sactd3_engine* e, int which, const float* m, const float* v, int64_t step) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   const int st = (int)step;
   if (which == SACTD3_LOG_ALPHA) {
@@ -1350,6 +1403,7 @@ static void pack_record(const sactd3_engine* e, float* rec, const float* ob, con
 int sactd3_rb_extend(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
   if (!e || !obs || !act || !rew || !nobs || !dones || n < 0) return e ? e->fail(SACTD3_EINVAL, "rb_extend: bad argument") : SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   const int64_t cap = e->cfg.rb_capacity;
   int done_rows = 0;
   while (done_rows < n) {
@@ -1389,6 +1443,7 @@ int sactd3_rb_layout(const sactd3_engine* e, int32_t out[4]) {
 int sactd3_rb_extend_device(sactd3_engine* e, const float* records, int n) {
   if (!e || !records || n < 0) return e ? e->fail(SACTD3_EINVAL, "rb_extend_device: bad argument") : SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   hipPointerAttribute_t at{};
   if (hipPointerGetAttributes(&at, records) != hipSuccess || at.type != hipMemoryTypeDevice) {
     (void)hipGetLastError();
@@ -1417,6 +1472,7 @@ int64_t sactd3_rb_len(const sactd3_engine* e) { return e ? e->rb_len : SACTD3_EI
 int sactd3_rb_sample(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "rb_sample: buffer is empty");
   e->cur_slot = 0;
   RCCHK(enqueue_gather(e, e->stream, e->ring, -1));
@@ -1428,6 +1484,7 @@ int sactd3_rb_sample(sactd3_engine* e) {
 int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
   if (!e || !idx) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (n != e->B) return e->fail(SACTD3_EINVAL, "rb_sample_with_indices: n must equal batch_size");
   std::vector<int> h(n);
   for (int i = 0; i < n; ++i) {
@@ -1445,6 +1502,7 @@ int sactd3_rb_sample_with_indices(sactd3_engine* e, const int64_t* idx, int n) {
 int sactd3_load_batch(sactd3_engine* e, const float* obs, const float* act, const float* rew, const float* nobs, const uint8_t* dones, int n) {
   if (!e || !obs || !act || !rew || !nobs || !dones) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (n != e->B) return e->fail(SACTD3_EINVAL, "load_batch: n must equal batch_size");
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<int> h(n);
@@ -1487,6 +1545,7 @@ int sactd3_read_batch(sactd3_engine* e, float* obs, float* act, float* rew, floa
 int sactd3_rb_fill_synthetic(sactd3_engine* e, int64_t n, uint64_t seed) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (n < 1 || n > e->cfg.rb_capacity) return e->fail(SACTD3_EINVAL, "rb_fill_synthetic: 1 <= n <= rb_capacity");
   FillArgs f{(float4*)e->ring, e->rec4, e->cx, e->cn, e->o, e->a, (long)n, seed, e->min_ac, e->max_ac};
   const long threads = (long)n * e->rec4;
@@ -1501,11 +1560,12 @@ int sactd3_rb_fill_synthetic(sactd3_engine* e, int64_t n, uint64_t seed) {
 int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
   if (!e || !eps || site < 0 || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (n < 1 || n > std::max(e->B, e->maxn)) return e->fail(SACTD3_EINVAL, "set_noise: too many rows");
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->eps[site], eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
   if (site == SACTD3_SITE_CRITIC)      // (every batch slot: injected draws are "sticky until cleared", whichever slot an iteration trains on)
-    for (int k = 1; k < 3; ++k) HIPCHK(hipMemcpy(e->bs[k].eps_c, eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
+    for (int k = 1; k < 4; ++k) HIPCHK(hipMemcpy(e->bs[k].eps_c, eps, sizeof(float) * (size_t)n * e->a, hipMemcpyHostToDevice));
   const int one = 1;
   HIPCHK(hipMemcpy(&e->ctl->inject_eps[site], &one, sizeof(int), hipMemcpyHostToDevice));
   return 0;
@@ -1513,6 +1573,7 @@ int sactd3_set_noise(sactd3_engine* e, int site, const float* eps, int n) {
 int sactd3_clear_noise(sactd3_engine* e, int site) {
   if (!e || site >= SACTD3_NUM_SITES) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   const int zeros[8] = {0};
   if (site < 0) HIPCHK(hipMemcpy(&e->ctl->inject_eps[0], zeros, sizeof(int) * 8, hipMemcpyHostToDevice));
@@ -1532,17 +1593,20 @@ int sactd3_read_noise(sactd3_engine* e, int site, float* eps, int n) {
 int sactd3_update_qnets(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   e->cur_slot = 0;
   return run_graph(e, G_Q, [&](hipStream_t s) { return enqueue_update_qnets(e, s, false, nullptr); });
 }
 int sactd3_update_actor(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   return run_graph(e, G_A, [&](hipStream_t s) { return enqueue_update_actor(e, s, 0); });
 }
 int sactd3_update_targ_nets(sactd3_engine* e, int64_t qnet_updates_so_far) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   const bool td3 = e->cfg.prefer_td3_over_sac;
   if (td3 || qnet_updates_so_far % e->cfg.crit_targ_update_freq == 0) return enqueue_polyak(e, e->stream, true, td3);
   return 0;
@@ -1550,6 +1614,7 @@ int sactd3_update_targ_nets(sactd3_engine* e, int64_t qnet_updates_so_far) {
 int sactd3_step(sactd3_engine* e, int do_actor) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step: buffer is empty");
   const int64_t updates = e->qnet_updates + 1;     // (the engine's own counter advances only once the iteration has been launched)
   const bool polyak = e->cfg.prefer_td3_over_sac || (updates % e->cfg.crit_targ_update_freq == 0);
@@ -1568,13 +1633,25 @@ static bool period_is_pipelined(const sactd3_engine* e) {
   const sactd3_config& c = e->cfg;
   return !c.prefer_td3_over_sac && c.autotune && c.actor_update_delay >= 1 && c.actor_update_delay <= 2 && opening_trunk_gathers(e);
 }
-static int enqueue_period(sactd3_engine* e, hipStream_t s) {
+// variant (pipelined form only): which batch slot the period's first iteration trains on (0: slot 0, 1: slot 3) -- the other one
+// receives the opening pair of the NEXT period, so consecutive periods alternate (chain_ready).  The pipelined form assumes its own
+// opening pair is already in place: sactd3_step_period runs the opening graph first when it is not.
+static int enqueue_period(sactd3_engine* e, hipStream_t s, int variant = 0) {
   const int n = e->cfg.actor_update_delay + 1;
-  const bool pipe = period_is_pipelined(e);
-  for (int i = 0; i < n; ++i)
-    RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n, pipe ? i : 0, pipe && i > 0, pipe && i == 0 ? n - 1 : 0));
+  if (!period_is_pipelined(e)) {
+    for (int i = 0; i < n; ++i) RCCHK(enqueue_step(e, s, i == 0 && e->cfg.actor_update_delay > 0, true, i + 1 < n));
+  } else {
+    const int P = variant ? 3 : 0, Pnext = variant ? 0 : 3;
+    RCCHK(enqueue_step(e, s, true, true, true, P, true, n - 1, Pnext, true));
+    for (int i = 1; i < n; ++i) RCCHK(enqueue_step(e, s, false, true, i + 1 < n, i, true));
+  }
   if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
   return 0;
+}
+// the opening pair of a period's first iteration into batch slot `slot`, without its counter ticks (enqueue_update_qnets, open_mode 1)
+static int enqueue_opening(sactd3_engine* e, hipStream_t s, int slot) {
+  bool policy_done = false;
+  return enqueue_update_qnets(e, s, true, nullptr, true, &policy_done, false, nullptr, slot, false, 1);
 }
 
 // One period of the actor schedule (orchestrator.py:345-349: iteration i with i % (delay + 1) == 0 runs the actor updates,
@@ -1588,9 +1665,22 @@ int sactd3_step_period(sactd3_engine* e) {
   const bool td3 = e->cfg.prefer_td3_over_sac;
   if (!td3 && e->cfg.crit_targ_update_freq != 1) return e->fail(SACTD3_ESTATE, "step_period: needs crit_targ_update_freq == 1");
   const int n = e->cfg.actor_update_delay + 1;
-  RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s); }));
+  if (!period_is_pipelined(e)) {
+    e->chain_ready = -1;
+    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s); }));
+    e->cur_slot = 0;
+  } else {
+    // chained periods: this period's opening pair is either left over from the previous one (chain_ready names the variant) or is
+    // produced now by the 2- / 3-node opening graph; the period graph then leaves the NEXT period's behind
+    const int v = e->chain_ready >= 0 ? e->chain_ready : 0;
+    const bool have = e->chain_ready >= 0;
+    e->chain_ready = -1;
+    if (!have) RCCHK(run_graph(e, G_OPENING, [&](hipStream_t s) { return enqueue_opening(e, s, 0); }));
+    RCCHK(run_graph(e, v ? G_PERIOD_B : G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s, v); }));
+    e->chain_ready = 1 - v;
+    e->cur_slot = n - 1;
+  }
   e->qnet_updates += n;
-  e->cur_slot = period_is_pipelined(e) ? n - 1 : 0;
   return 0;
 }
 
@@ -1607,7 +1697,11 @@ int sactd3_instantiate_graphs(sactd3_engine* e) {
       RCCHK(run_graph(e, G_STEP00 + (a ? 2 : 0) + (py ? 1 : 0), [&](hipStream_t s) { return enqueue_step(e, s, a, py); }, false));
     }
   if (same_branch && e->cfg.actor_update_delay > 0) {
-    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s); }, false));
+    RCCHK(run_graph(e, G_PERIOD, [&](hipStream_t s) { return enqueue_period(e, s, 0); }, false));
+    if (period_is_pipelined(e)) {
+      RCCHK(run_graph(e, G_PERIOD_B, [&](hipStream_t s) { return enqueue_period(e, s, 1); }, false));
+      RCCHK(run_graph(e, G_OPENING, [&](hipStream_t s) { return enqueue_opening(e, s, 0); }, false));
+    }
   }
   return 0;
 }
@@ -1736,8 +1830,8 @@ int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_
 
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
   if (!e) return SACTD3_EINVAL;
-  static const int map[5] = {G_Q, G_A, G_STEP01, G_STEP11, G_PERIOD};
-  if (which_graph < 0 || which_graph > 4) return SACTD3_EINVAL;
+  static const int map[6] = {G_Q, G_A, G_STEP01, G_STEP11, G_PERIOD, G_OPENING};
+  if (which_graph < 0 || which_graph > 5) return SACTD3_EINVAL;
   int w = map[which_graph];
   if (!e->graphs[w] && (which_graph == 2 || which_graph == 3)) w -= 1;   // the no-Polyak variant, if that is the one in use
   return e->graph_nodes[w];
@@ -1746,6 +1840,7 @@ int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
 int sactd3_time_kernel(sactd3_engine* e, const char* kernel, int iters, float* usec) {
   if (!e || !kernel || !usec || iters < 1) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   hipEvent_t t0, t1;
   HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
   int rc = 0;
@@ -1786,6 +1881,7 @@ int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, 
                       float* usec, double* flops, double* bytes, int64_t* threads) {
   if (!e || iters < 1 || max_nodes < 1 || !usec) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "time_nodes: buffer is empty");
   const bool act = do_actor != 0 && e->cfg.actor_update_delay > 0;
   const bool period = do_actor == 2 && e->cfg.actor_update_delay > 0 && (e->cfg.prefer_td3_over_sac || e->cfg.crit_targ_update_freq == 1);
@@ -1836,6 +1932,7 @@ int sactd3_time_nodes(sactd3_engine* e, int do_actor, int iters, int max_nodes, 
 int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec, double* algo_bytes) {
   if (!e || !usec || batch < 1 || iters < 1) return SACTD3_EINVAL;
   USE_DEVICE(e);
+  CHAIN_BREAK(e);
   if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "gather sweep: buffer is empty");
   if ((long long)batch * e->rec4 >= (1ll << 31)) return e->fail(SACTD3_EINVAL, "gather sweep: batch too large");
   float *X = nullptr, *Xn = nullptr, *rw = nullptr, *dn = nullptr; int* ix = nullptr;

@@ -469,7 +469,7 @@ struct NtGrp {               // one group of nets sharing an input and a paramet
   int ring; int ring_off; int sctr_add; const int* ring_idx;
 };
 struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block = one 16 x 16 output tile, K split over the 4 waves
-  NtGrp g[3]; int npg;                      // blockIdx.z = grp * npg + net-in-group
+  NtGrp g[5]; int npg;                      // blockIdx.z = grp * npg + net-in-group
   int ld_in; long in_ns;
   int oW, ldw, oBias, oG, oBe; long p_ns;   // offsets inside a net's parameter block: W [N][ldw], bias (-1: none), LN affine of the A rows
   int ldy; long y_ns;
@@ -480,9 +480,10 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   float* adam_out; double* adam_pw; float lr, b1, b2;   // with tick0: publish this step's Adam scalars
   unsigned w1_magic;                        // ceil(2^32 / ldw1) for the W1 parking index arithmetic
   // Fused replay sampling: groups with NtGrp::ring read their rows straight from the replay ring, and `gblocks` extra blocks at the
-  // end of the grid do the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.  Up to two
-  // gathers ride (gb_each blocks each: the samples of the two critic-only iterations of a period, into their own batch slots).
-  int nt_blocks; int gblocks; int gb_each; GatherArgs ga[2];
+  // end of the grid do the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.  Up to three
+  // gathers ride (gb_each blocks each: the samples of the two critic-only iterations of a period and of the NEXT period's first
+  // iteration, into their own batch slots).
+  int nt_blocks; int gblocks; int gb_each; GatherArgs ga[3];
   // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
   int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
   int xr;                                // XCD row-block groups of the tile placement (xcd_tile; unfused launches), 0 = row-major numbering
@@ -491,7 +492,7 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // (k_alpha_step's body): nothing in this launch reads log_alpha or the noise counter, the next kernel does.
   int alpha_block; AlphaArgs al;
   // ... and the noise draws of the actor tail that follows this launch (see NoiseJob): nz_n jobs, nz[i].blocks blocks each
-  int nz_n; NoiseJob nz[3]; const DevCtl* nz_ctl;
+  int nz_n; NoiseJob nz[5]; const DevCtl* nz_ctl;
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -515,7 +516,17 @@ __device__ __forceinline__ void riding_body(const NtArgs& p, int x) {
   x -= p.nz[0].blocks;
   if (p.nz_n > 1 && x < p.nz[1].blocks) { noise_body(p.nz[1], p.nz_ctl, x); return; }
   x -= p.nz[1].blocks;
-  if (p.nz_n > 2) noise_body(p.nz[2], p.nz_ctl, x);
+  if (p.nz_n > 2 && x < p.nz[2].blocks) { noise_body(p.nz[2], p.nz_ctl, x); return; }
+  x -= p.nz[2].blocks;
+  if (p.nz_n > 3 && x < p.nz[3].blocks) { noise_body(p.nz[3], p.nz_ctl, x); return; }
+  x -= p.nz[3].blocks;
+  if (p.nz_n > 4) noise_body(p.nz[4], p.nz_ctl, x);
+}
+// riding gather block x of a trunk launch (up to three gathers of gb_each blocks)
+__device__ __forceinline__ void riding_gather(const NtArgs& p, int x) {
+  if (x < p.gb_each) gather_body(p.ga[0], x);
+  else if (x < 2 * p.gb_each) gather_body(p.ga[1], x - p.gb_each);
+  else gather_body(p.ga[2], x - 2 * p.gb_each);
 }
 
 // PRO: 0 none, 1 LayerNorm+ReLU, 2 ReLU.  FUSE1: the A rows are produced by a fused first layer.
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
   if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
     const int x = (int)blockIdx.x - p.nt_blocks;
-    if (x < p.gblocks) { if (blockIdx.z == 0) { if (x < p.gb_each) gather_body(p.ga[0], x); else gather_body(p.ga[1], x - p.gb_each); } }
+    if (x < p.gblocks) { if (blockIdx.z == 0) riding_gather(p, x); }
     else if (blockIdx.z != 0) { }
     else riding_body(p, x - p.gblocks);
     return;
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_nt64(NtArgs p) {       // Y[M,
   const int tile_blocks = (p.gblocks || p.alpha_block) ? p.nt_blocks : (int)gridDim.x;
   if ((int)blockIdx.x >= tile_blocks) {           // (block-uniform) riding blocks: replay gathers (256-thread instances), a pending temperature step
     const int x = (int)blockIdx.x - tile_blocks;
-    if (NTH == 256 && x < p.gblocks) { if (x < p.gb_each) gather_body(p.ga[0], x); else gather_body(p.ga[1], x - p.gb_each); }
+    if (NTH == 256 && x < p.gblocks) riding_gather(p, x);
     else if (x >= p.gblocks && p.alpha_block) alpha_body(p.al);
     return;
   }
@@ -1963,11 +1974,16 @@ __global__ __launch_bounds__(256) void k_actor_tail2(ActorTail a, ActorTail b, i
   if ((int)blockIdx.x < nb_a) actor_tail_body(a, blockIdx.x);
   else actor_tail_body(b, blockIdx.x - nb_a);
 }
-// ... three (a pipelined period: the last actor update's temperature draw + the next-action passes of the two critic-only iterations)
-__global__ __launch_bounds__(256) void k_actor_tail3(ActorTail a, ActorTail b, ActorTail c, int nb_a, int nb_b) {
-  if ((int)blockIdx.x < nb_a) actor_tail_body(a, blockIdx.x);
-  else if ((int)blockIdx.x < nb_a + nb_b) actor_tail_body(b, blockIdx.x - nb_a);
-  else actor_tail_body(c, blockIdx.x - nb_a - nb_b);
+// ... up to five (a pipelined period: the last actor update's temperature draw + the next-action passes of the two critic-only
+// iterations [+ the next period's opening pair: next-action pass and policy pass]); nb blocks per tail, n tails
+struct ActorTail5 { ActorTail t[5]; int nb; int n; };
+__global__ __launch_bounds__(256) void k_actor_tail5(ActorTail5 p) {
+  const int which = (int)blockIdx.x / p.nb, blk = (int)blockIdx.x - which * p.nb;       // (selects, not a run-time index: kernarg loads stay scalar)
+  if (which == 0) actor_tail_body(p.t[0], blk);
+  else if (which == 1) actor_tail_body(p.t[1], blk);
+  else if (which == 2) actor_tail_body(p.t[2], blk);
+  else if (which == 3) actor_tail_body(p.t[3], blk);
+  else actor_tail_body(p.t[4], blk);
 }
 
 // Narrow heads (nh <= 8: Hopper's SAC head 2 x 3, HalfCheetah's TD3 head 6 ...).  The general kernel above spends two block
@@ -2124,10 +2140,13 @@ __global__ __launch_bounds__(16 * RPB) void k_actor_tail_s2(ActorTail a, ActorTa
   else actor_tail_s_body<RPB>(b, blockIdx.x - nb_a);
 }
 template <int RPB>
-__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s3(ActorTail a, ActorTail b, ActorTail c, int nb_a, int nb_b) {
-  if ((int)blockIdx.x < nb_a) actor_tail_s_body<RPB>(a, blockIdx.x);
-  else if ((int)blockIdx.x < nb_a + nb_b) actor_tail_s_body<RPB>(b, blockIdx.x - nb_a);
-  else actor_tail_s_body<RPB>(c, blockIdx.x - nb_a - nb_b);
+__global__ __launch_bounds__(16 * RPB) void k_actor_tail_s5(ActorTail5 p) {
+  const int which = (int)blockIdx.x / p.nb, blk = (int)blockIdx.x - which * p.nb;
+  if (which == 0) actor_tail_s_body<RPB>(p.t[0], blk);
+  else if (which == 1) actor_tail_s_body<RPB>(p.t[1], blk);
+  else if (which == 2) actor_tail_s_body<RPB>(p.t[2], blk);
+  else if (which == 3) actor_tail_s_body<RPB>(p.t[3], blk);
+  else actor_tail_s_body<RPB>(p.t[4], blk);
 }
 
 struct CriticTail {

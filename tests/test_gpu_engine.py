@@ -669,15 +669,17 @@ def test_period_graph_equals_single_iterations(algo, env, B):
         eng.rb_extend(*[t.numpy() for t in synth_transitions(3000, o, a, bound, seed=23)])
         if mode == "period":
             assert eng.run_iterations(1, 10) == 11          # iterations 1, 2 singly, periods 3-5 and 6-8, then 9, 10
-            # SAC: the period's last temperature step rides in the next iteration's first launch (one node fewer), and the two
-            # critic-only iterations' sampling + next-action passes (trunk launch(es) + tail: 2 nodes at narrow observations, 3 at
-            # wide ones) ride ahead in the first iteration's last actor-trunk / tail launches (pipelined period, csrc/engine.hip BatchSlot)
+            # SAC (pipelined, chained periods -- csrc/engine.hip BatchSlot / chain_ready): the period's last temperature step rides in the
+            # next iteration's first launch (one node fewer); the critic-only iterations' sampling + next-action passes (trunk launch(es)
+            # + tail: 2 nodes at narrow observations, 3 at wide ones) run ahead in the first iteration's last actor-trunk / tail launches,
+            # and so does the opening pair of the NEXT period -- so a period graph holds no opening nodes at all; a 2- / 3-node opening
+            # graph runs only when no precomputed pair is there (the first period, or after any state change in between)
             c0, c1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
             if algo == "sac":
                 opening = 3 if env == "humanoid" else 2
-                assert eng.graph_kernel_count(4) == c1 - 1 + 2 * (c0 - opening)
+                assert eng.graph_kernel_count(4) == c1 - 1 + 2 * (c0 - opening) - opening and eng.graph_kernel_count(5) == opening
             else:
-                assert eng.graph_kernel_count(4) == c0 * 2 + c1
+                assert eng.graph_kernel_count(4) == c0 * 2 + c1 and eng.graph_kernel_count(5) == 0
         else:
             for i in range(1, 11):
                 eng.step(i % 3 == 0)
@@ -692,6 +694,48 @@ def test_period_graph_equals_single_iterations(algo, env, B):
         with pytest.raises(P.EngineError):
             eng.step_period()
         assert eng.run_iterations(0, 7) == 7 and eng.get_adam_state(_lib.CRITICS)[2] == 7
+
+
+@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("sac", "humanoid", 1024), ("sac", "halfcheetah", 64), ("td3", "halfcheetah", 256)])
+def test_chained_periods_with_state_changes_in_between_equal_single_iterations(algo, env, B):
+    """A SAC period graph leaves the NEXT period's opening pair (sample, gather, next-action pass, first policy pass) precomputed;
+    that is only valid while nothing it depends on changes.  Interleave periods with everything a caller may do between two of them
+    -- new rows in the ring (rb.extend, orchestrator.py:100-113), acting (predict), a parameter write, single iterations, an API-path
+    update -- and require the result to be bit-identical to the same sequence issued as single iterations (sactd3_step)."""
+    res = []
+    for mode in ("period", "single"):
+        ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=6)
+        rows = [t.numpy() for t in synth_transitions(3000, o, a, bound, seed=29)]
+        eng.rb_extend(*[r[:2000] for r in rows])
+        it = [0]
+
+        def run(n):
+            if mode == "period":
+                it[0] = eng.run_iterations(it[0], n)
+            else:
+                for _ in range(n):
+                    eng.step(it[0] % 3 == 0)
+                    it[0] += 1
+        run(6)                                                  # two periods back to back: the second starts from the precomputed pair
+        eng.rb_extend(*[r[2000:2600] for r in rows])           # the ring grows: the next sample is drawn from 2600 rows
+        run(3)
+        acted = eng.predict(rows[0][:4], True)                  # acting in between reads the actor only
+        run(3)
+        eng.set_params(_lib.ACTOR, eng.get_params(_lib.ACTOR))  # a parameter write (same values)
+        run(4)                                                  # a period, then a single iteration ...
+        run(5)                                                  # ... two more singles, then a period
+        eng.rb_sample(); eng.update_qnets(); eng.update_targ_nets(22)    # an API-path update on a fresh sample
+        it[0] += 1                                              # (counts as iteration 21: not a multiple of 3)
+        run(2)                                                  # singles 22, 23 (whole periods only start at multiples of 3)
+        run(6)                                                  # periods 24-26, 27-29
+        res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR_TARGET),
+                    eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"], eng.read_noise(_lib.SITE_CRITIC), acted,
+                    eng.get_adam_state(_lib.CRITICS)[2], eng.get_adam_state(_lib.ACTOR)[2], np.array(list(eng.read_metrics().values()))))
+        if mode == "period" and algo == "sac":
+            assert eng.graph_kernel_count(5) > 0                # the opening graph exists: the chained form was in use
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    assert res[0][8] == 30 and res[0][9] == 18
 
 
 def test_graphs_can_be_instantiated_ahead_of_the_first_step():

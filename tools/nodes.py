@@ -13,9 +13,9 @@ t0 = time.perf_counter(); bench.run_steps(eng, it, 3000); eng.sync(); dt = time.
 print(f"{name}: {3000/dt:.0f} it/s  {dt/3000*1e6:.2f} us/iteration")
 eng.close()
 nu, rl, _ = bench.node_budget(w, name, 0, dt / 3000 * 1e3, iters)
-for k in ("sum_critic_only_us", "sum_critic_plus_2_actor_us", "sum_per_iteration_us", "unaccounted_us_per_iteration"):
+for k in ("sum_critic_only_us", "sum_critic_plus_2_actor_us", "sum_period_us", "sum_per_iteration_us", "unaccounted_us_per_iteration"):
     print(k, round(nu[k], 2))
-for n, us in nu["critic_plus_2_actor"]:
+for n, us in nu["period_of_3_iterations"]:
     print(f"  {us:7.2f}  {n}")
 for r in rl[:8]:
     print(f"{r['kernel']:28s} grids {r['grids']} {r['avg_launch_us']:6.2f} us x{r['launches_per_iteration']:.2f}/it  {r['bound']} frac {r['frac']:.3f}  share {r['share_of_node_time']:.3f}")
