@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle.sac_td3_ref import DetPolicy, Hps, QNet, RefAgent, SquashedGaussPolicy
+from tests import helpers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = {"hopper": (11, 3, 1.0), "halfcheetah": (17, 6, 1.0), "humanoid": (376, 17, 0.4)}
@@ -125,5 +126,8 @@ def test_engine_follows_golden_trajectory(algo, env):
         want = fx["losses"][i]
         keys = ["loss/qf_loss", "loss/actor_loss", "loss/alpha_loss", "vitals/alpha"]
         for k, w in zip(keys, want):
-            if np.isfinite(w):
-                np.testing.assert_allclose(m[k], w, rtol=1e-5 * (1 + 3 * i) + 1e-6, atol=1e-5 * (1 + 3 * i), err_msg=f"iter {i} {k}")
+            if np.isfinite(w):   # (the fixture holds float64 printouts of float32 losses: 1e-6 of slack for that; then 1e-5 on the first
+                                 #  iteration, 2e-5 flat afterwards -- the trajectory rule of tests/test_gpu_engine.py)
+                tol = 1e-5 if i == 0 else 2e-5
+                helpers.observe(f"engine_follows_golden_trajectory[{algo}-{env}]", f"iter {i} scalars", abs(m[k] - w) / (1.0 + abs(w)))
+                np.testing.assert_allclose(m[k], w, rtol=tol + 1e-6, atol=tol, err_msg=f"iter {i} {k}")

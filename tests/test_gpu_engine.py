@@ -442,11 +442,18 @@ def test_crit_targ_update_freq_gate():
 
 # ------------------------------------------------------------------------------------------ trajectories
 
-# Trajectory comparisons (several Adam steps from a common start, drift included): scalar tolerance per iteration i is
-# TRAJ_TOL (1 + i) -- 1e-5 (north_star) on the first, never more than 1e-5 more per iteration; parameters after the steps: per
-# state_dict key at most TRAJ_BAD of a matrix's elements / TRAJ_VEC_BAD elements of a vector beyond atol 2e-5 + rtol 1e-5
-# (tests/helpers.py: sign-like Adam steps of near-zero gradients).  Values set from gpurun_out/parity_observed.json (<= 2x observed).
-TRAJ_TOL, TRAJ_BAD, TRAJ_VEC_BAD = 1e-5, 5e-2, 2
+# Trajectory comparisons (7-9 iterations from a common start, the drift of two fp32 Adam implementations included).  Every bound is
+# set from what the tests observe on the GPU (tests/helpers.py:observe -> gpurun_out/parity_observed.json), at most ~2x above it:
+#   scalars    |engine - oracle| <= tol (1 + |oracle|): 1e-5 (north_star) on the first iteration, 2e-5 FLAT afterwards
+#              (observed: <= 2.2e-7 on the API-path trajectories, <= 8.0e-6 over the 7 fused iterations at the BASELINE shapes);
+#   parameters per state_dict key: <= TRAJ_BAD of a matrix's elements and <= TRAJ_VEC_BAD elements of a vector beyond atol 2e-5 +
+#              rtol 1e-5 (observed: 0 everywhere except Humanoid's 256 x 393 first critic layer after 7 iterations, 2.5e-2 / 1), and no
+#              element further than TRAJ_CAP x lr from the oracle's (observed: <= 0.24 lr)
+TRAJ_BAD, TRAJ_BAD_WIDE, TRAJ_VEC_BAD, TRAJ_CAP = 2e-3, 5e-2, 2, 0.5
+
+
+def TRAJ_TOL(i):
+    return 1e-5 if i == 0 else 2e-5
 
 
 def push_adam(eng, ref):
@@ -511,13 +518,13 @@ def test_trajectory_api_path(algo, env):
     rec = f"trajectory_api_path[{algo}-{env}]"
     for i, (want, got) in enumerate(logs):
         # error growth through the (chaotic) optimisation: north_star's 1e-5 on the first iteration, at most one more 1e-5 per iteration
-        scalars_close(rec, i, got, want, TRAJ_TOL * (1 + i))
+        scalars_close(rec, i, got, want, TRAJ_TOL(i))
     assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 9, "critics", max_bad_frac=TRAJ_BAD,
-                        layout=crit_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec)
+                        layout=crit_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec, max_lr_steps=TRAJ_CAP)
     assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 6, "actor", max_bad_frac=TRAJ_BAD,
-                        layout=actor_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec)
+                        layout=actor_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec, max_lr_steps=TRAJ_CAP)
     assert_params_close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), ref.hps.qnets_lr, 9, "critic targets",
-                        layout=crit_layout(ref), record=rec)
+                        layout=crit_layout(ref), record=rec, max_lr_steps=TRAJ_CAP)
 
 
 RESYNC_TOL = 3e-5   # flat: |engine - oracle| <= RESYNC_TOL (1 + |oracle|) on every iteration (fp32 noise floor of the critic loss, see the docstring)
@@ -604,7 +611,7 @@ def test_fused_step_against_oracle_at_baseline_shapes(algo, env, B, cap):
         b = ref.to_batch(*[r[idx] for r in rows])
         want = {k: float(v) for k, v in ref.iteration(b, i, noise).items()}
         got = eng.read_metrics()
-        scalars_close(rec, i, got, want, TRAJ_TOL * (1 + i))
+        scalars_close(rec, i, got, want, TRAJ_TOL(i))
         if i == 0:   # the gradients the fused launches left behind (critics; the SECOND actor update), per key, against autograd
             # (critics only: the actor arena holds the SECOND update's gradients, taken from parameters that are already one
             #  sign-like fp32 Adam step apart, tests/helpers.py; the actor's gradients are compared per key by the intermediates tests)
@@ -614,15 +621,16 @@ def test_fused_step_against_oracle_at_baseline_shapes(algo, env, B, cap):
                 for (k, _), gr in zip(ref.qnets[qi].named_parameters(), ref.trace["q_grads"][qi * len(gd):(qi + 1) * len(gd)]):
                     gclose(gd[k], gr, name=f"fused step: critic{qi} grad {k}")
     n_act = delay * len([i for i in range(n_iter) if i % (delay + 1) == 0])
-    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, n_iter, "critics", max_bad_frac=TRAJ_BAD,
-                        layout=crit_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec)
+    bad = TRAJ_BAD_WIDE if env == "humanoid" else TRAJ_BAD
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, n_iter, "critics", max_bad_frac=bad,
+                        layout=crit_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec, max_lr_steps=TRAJ_CAP)
     assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, n_act, "actor", max_bad_frac=TRAJ_BAD,
-                        layout=actor_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec)
+                        layout=actor_layout(ref), vec_bad=TRAJ_VEC_BAD, record=rec, max_lr_steps=TRAJ_CAP)
     assert_params_close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), ref.hps.qnets_lr, n_iter, "critic targets",
-                        layout=crit_layout(ref), record=rec)
+                        layout=crit_layout(ref), record=rec, max_lr_steps=TRAJ_CAP)
     if algo == "td3":
         assert_params_close(eng.get_params(_lib.ACTOR_TARGET), flat_actor(ref, ref.actor_target), ref.hps.actor_lr, n_act, "actor target",
-                            layout=actor_layout(ref), record=rec)
+                            layout=actor_layout(ref), record=rec, max_lr_steps=TRAJ_CAP)
     else:
         close(eng.get_params(_lib.LOG_ALPHA)[0], ref.log_alpha, rtol=1e-5, atol=1e-6, name="log_alpha")
     _, _, tq = eng.get_adam_state(_lib.CRITICS)
@@ -979,8 +987,8 @@ def test_update_results_are_zero_dim_device_tensors():
 
 # ------------------------------------------------------------------------------------------ config corners
 
-# one iteration = a critic step and TWO actor steps on top of each other (the second starts from the first's fp32 result): 2e-5
-CORNER_TOL = 2e-5
+# one iteration = a critic step and TWO actor steps on top of each other: north_star's 1e-5 (observed <= 2.7e-6 over all corners and odd shapes)
+CORNER_TOL = 1e-5
 
 
 @pytest.mark.parametrize("algo,env,B,hp", [
@@ -1013,8 +1021,8 @@ def test_one_iteration_config_corners(algo, env, B, hp):
     rec = f"one_iteration_config_corners[{algo}-{env}-{B}-{sorted(hp.items())}]"
     scalars_close(rec, 0, got, want, CORNER_TOL)
     assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics", layout=crit_layout(ref), record=rec)
-    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=1e-2,
-                        layout=actor_layout(ref), vec_bad=4, record=rec)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=1e-3,
+                        layout=actor_layout(ref), vec_bad=1, record=rec)
     close(eng.get_params(_lib.CRITICS_TARGET), flat_critics(ref, ref.qnets_target), rtol=1e-5, atol=1e-5, name="targets")
     if algo == "td3":
         close(eng.get_params(_lib.ACTOR_TARGET), flat_actor(ref, ref.actor_target), rtol=1e-5, atol=1e-5, name="actor target")
@@ -1061,10 +1069,10 @@ def test_one_iteration_odd_dimensions(algo, o, a, B):
     got = eng.read_metrics()
     rec = f"one_iteration_odd_dimensions[{algo}-{o}-{a}-{B}]"
     scalars_close(rec, 0, got, want, CORNER_TOL)
-    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics", max_bad_frac=5e-3,
-                        layout=crit_layout(ref), vec_bad=2, record=rec)
-    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=2e-2,
-                        layout=actor_layout(ref), vec_bad=8, record=rec)
+    assert_params_close(eng.get_params(_lib.CRITICS), flat_critics(ref, ref.qnets), ref.hps.qnets_lr, 1, "critics", max_bad_frac=1e-3,
+                        layout=crit_layout(ref), vec_bad=1, record=rec)
+    assert_params_close(eng.get_params(_lib.ACTOR), flat_actor(ref, ref.actor), ref.hps.actor_lr, 2, "actor", max_bad_frac=1e-3,
+                        layout=actor_layout(ref), vec_bad=1, record=rec)
     x = torch.randn(3, o, generator=g)
     close(eng.predict(x, explore=False), ref.predict(x, explore=False), name="predict")
     # and the fused iteration runs on these shapes too
