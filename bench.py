@@ -558,7 +558,9 @@ def main():
 
     # seed = GPU index, one independent learner per GPU
     eng = _DryEngine() if args.dry_run_ranks else make_engine(w, seed=rank, device_id=local)
-    it = run_steps(eng, 0, args.warmup)
+    # iteration numbers: the warm-up is numbered so that the timed window starts at a multiple of DELAY + 1 -- an iteration with the
+    # actor updates, like iteration 0 of the reference loop (orchestrator.py:345-349) -- whatever --warmup is
+    it = run_steps(eng, (-args.warmup) % (DELAY + 1), args.warmup)
     eng.sync()
     gpu_sync()
     if dist:

@@ -1079,6 +1079,9 @@ static int run_graph_slot(sactd3_engine* e, hipGraphExec_t* slot, int* nodes, F&
     he = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     if (he != hipSuccess) return e->fail(SACTD3_EHIP, "hipGraphInstantiate", he);
+    // move the executable graph's launch resources to the device now, not inside its first launch (a loop that instantiates ahead --
+    // sactd3_instantiate_graphs -- then pays nothing extra the first time each graph runs); not every runtime implements it: best effort
+    if (hipGraphUpload(*slot, e->stream) != hipSuccess) (void)hipGetLastError();
   }
   if (launch) HIPCHK(hipGraphLaunch(*slot, e->stream));
   return 0;
@@ -1780,11 +1783,24 @@ int sactd3_device_handles(sactd3_engine* e, void** stream, float** metrics) {
   return 0;
 }
 
+// Wait for the engine's stream: poll it for up to 2 ms (a blocking hipStreamSynchronize sleeps on an interrupt and wakes up tens of
+// microseconds after the last kernel has finished -- as long as an iteration takes), then block.
+static int stream_wait(sactd3_engine* e) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(e->stream);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return e->fail(SACTD3_EHIP, "hipStreamQuery", q);
+    if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 int sactd3_sync(sactd3_engine* e) {
   if (!e) return SACTD3_EINVAL;
   USE_DEVICE(e);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
+  return stream_wait(e);
 }
 
 // ---- introspection
