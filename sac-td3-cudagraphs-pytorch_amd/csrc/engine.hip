@@ -99,6 +99,7 @@ struct sactd3_engine {
   DevCtl* ctl = nullptr;
   float *min_ac = nullptr, *max_ac = nullptr, *scale = nullptr, *bias = nullptr;
   float *Pa = nullptr, *Ta = nullptr, *Ga = nullptr, *Ma = nullptr, *Va = nullptr;
+  float *Ta2 = nullptr, *Ta3 = nullptr;     // TD3 period graphs: the actor target one / two Polyak steps ahead (TnArgs::T2, T3)
   float *Pc = nullptr, *Tc = nullptr, *Gc = nullptr, *Mc = nullptr, *Vc = nullptr;
   float *la = nullptr, *gscale = nullptr;
   float* ring = nullptr; float* stage_dev = nullptr;
@@ -432,6 +433,7 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
     }
     r.nets = nets; r.g_ns = g.g_ns; r.G = g.G;
     r.apply = g.apply; r.P = g.P; r.Mo = g.Mo; r.Vo = g.Vo; r.T = g.T; r.tau = g.tau; r.adam = g.adam; r.b1 = g.b1; r.b2 = g.b2; r.eps = g.eps;
+    r.T2 = g.T2; r.T3 = g.T3;
     r.part = g.part; r.pstride = g.pstride; r.part_s = g.part_s;
     r.loss_part = g.loss_part; r.loss_n = g.loss_n; r.loss_stride = g.loss_stride; r.loss_off = g.loss_off; r.loss_scale = g.loss_scale;
     r.loss_dst = g.loss_dst; r.tick = g.tick; r.tick_extra = tick_extra;
@@ -900,6 +902,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = clip ? nullptr : polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_a;
+    if (td3 && g.T && (ahead > 0 || chain_slot >= 0)) { g.T2 = e->Ta2; g.T3 = e->Ta3; }   // the actor target of the next two Polyak updates, now
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
     g.loss_part = e->part_sa; g.loss_n = e->nblk4; g.loss_stride = 2; g.loss_off = 1; g.loss_scale = 1.0f / (float)B;
     g.loss_dst = &e->ctl->metrics[SACTD3_M_ACTOR_LOSS]; g.tick = (td3 && !clip) ? &e->ctl->noise_ctr : nullptr;
@@ -913,6 +916,54 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     a.targ = polyak_targ; a.tau = c.polyak;
     a.tick = td3 ? &e->ctl->noise_ctr : nullptr;
     RCCHK(launch_adam(e, s, a));
+  }
+  if (td3 && (ahead > 0 || chain_slot >= 0)) {
+    // TD3, pipelined period (see BatchSlot): the online actor is final until the next period's actor updates, and the TARGET actor
+    // of the following iterations is a fixed sequence of lerps towards it -- Ta (after this update's Polyak step), Ta2, Ta3 (written by
+    // the Adam epilogue above).  So the sampling, gather and next-action pass of the period's critic-only iterations, and the opening
+    // pair of the next period's first iteration (its next-action pass through Ta3 / Ta2, its first policy pass through Pa), run here
+    // as ONE trunk + tail pair.  Streams: iteration k samples with sample_ctr + (k - 1) and draws its smoothing noise with noise
+    // counter + (k - 1) (the counter already counts this update's tick; one tick per critic update in between); the next period's
+    // first iteration with + ahead -- the values their own opening launches would use.
+    e->node_role = chain_slot >= 0 ? "next-action passes ahead & next period's opening" : "next-action passes ahead";
+    const float* Tk[3] = {e->Ta, e->Ta2, e->Ta3};
+    const int mode = c.targ_actor_smoothing ? 1 : 0;
+    TrunkGrp g[5] = {};
+    TrunkTicks tk{nullptr, nullptr, nullptr, nullptr, 0.f};
+    ActorTail5 T{};
+    bool eps_ready = false;
+    int ng = 0;
+    auto add_next = [&](int slot_k, int order) {
+      const sactd3_engine::BatchSlot& S = e->bs[slot_k];
+      g[ng] = TrunkGrp{S.Xn, Tk[order], e->ah_z1[ng], e->ah_z2[ng], nullptr, nullptr, nullptr, e->ldc};
+      g[ng].ring = true; g[ng].sctr_add = order; g[ng].ring_idx = S.idx;
+      tk.gather[tk.ngather++] = gather_args(e, e->ring, -1, slot_k, order);
+      if (mode == 1) { tk.noise[tk.nnoise] = noise_job(e, SACTD3_SITE_CRITIC, 0u, order, B); tk.noise[tk.nnoise++].eps = S.eps_c; tk.noise_taken = &eps_ready; }
+      T.t[ng] = tail_args(e, e->ah_z2[ng], Tk[order], B, mode, 0, SACTD3_SITE_CRITIC, 0u, S.Xn, e->ldc, e->o, S.logp_n);
+      T.t[ng].eps = S.eps_c; T.t[ng].ctr_add = order;
+      ++ng;
+    };
+    for (int k = 1; k <= ahead; ++k) add_next(k, k - 1);
+    if (chain_slot >= 0) {
+      add_next(chain_slot, ahead);
+      const sactd3_engine::BatchSlot& S = e->bs[chain_slot];
+      g[ng] = TrunkGrp{S.X, e->Pa, e->ah_z1[ng], e->ah_z2[ng], e->a_xh1, e->a_h1, e->a_rs1, 0};
+      g[ng].ring = true; g[ng].sctr_add = ahead; g[ng].ring_idx = S.idx;
+      T.t[ng] = tail_args(e, e->ah_z2[ng], e->Pa, B, 0, 1, SACTD3_SITE_ACTOR0, 16u, e->Xp, e->ldc, e->o, e->logp_pi);
+      T.t[ng].obs_src = S.X; T.t[ng].lds = e->ldc;                      // Xp = [s | pi(s)] (the gather above has filled S.X)
+      ++ng;
+    }
+    tk.force_ks = 4; tk.no_tiled64 = true;      // (the launch shapes of the single-net passes: ring rows, riding gathers, bit-equal results)
+    RCCHK(enqueue_trunk(e, s, e->ldc, e->o, B, e->La, 0, ng, 1, g, tk));
+    if (ahead) { T.t[0].tick = &e->ctl->sample_ctr; T.t[0].tick_add = ahead - 1; }      // every reader of the index streams is done
+    for (int i = 0; i < ng; ++i) T.t[i].eps_ready = eps_ready;
+    for (int i = ng; i < 5; ++i) T.t[i] = T.t[0];
+    const int rpb = tail_rows_per_block(T.t[0]);
+    T.nb = (B + rpb - 1) / rpb; T.n = ng;
+    const double fl = 2.0 * ng * B * (double)HID * e->nh;
+    const double by = 4.0 * ng * ((double)B * HID + (double)e->nh * (HID + 1) + 2.0 * HID + (double)B * (3 * e->a + 2)) + (chain_slot >= 0 ? 8.0 * (double)B * (HID + e->o) : 0.0);
+    if (rpb == 4) LAUNCH("k_actor_tail_s5<4>", fl, by, k_actor_tail_s5<4>, dim3(ng * T.nb), dim3(64), T);
+    else LAUNCH("k_actor_tail5", fl, by, k_actor_tail5, dim3(ng * T.nb), dim3(256), T);
   }
   e->node_role = (j & 1) ? "actor1/alpha" : "actor0/alpha";
   if (!td3) {
@@ -1193,6 +1244,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
   RCCHK(dalloc(e, &e->scale, e->a4)); RCCHK(dalloc(e, &e->bias, e->a4));
   RCCHK(dalloc(e, &e->Pa, e->La.size)); RCCHK(dalloc(e, &e->Ta, e->La.size)); RCCHK(dalloc(e, &e->Ga, e->La.size));
   RCCHK(dalloc(e, &e->Ma, e->La.size)); RCCHK(dalloc(e, &e->Va, e->La.size));
+  RCCHK(dalloc(e, &e->Ta2, e->La.size)); RCCHK(dalloc(e, &e->Ta3, e->La.size));
   RCCHK(dalloc(e, &e->Pc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Tc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Gc, 2 * e->Lc.size));
   RCCHK(dalloc(e, &e->Mc, 2 * e->Lc.size)); RCCHK(dalloc(e, &e->Vc, 2 * e->Lc.size));
   RCCHK(dalloc(e, &e->la, 4)); RCCHK(dalloc(e, &e->gscale, 4));
@@ -1629,12 +1681,23 @@ int sactd3_step(sactd3_engine* e, int do_actor) {
   return 0;
 }
 
-// Is the period graph built in its pipelined form (see BatchSlot)?  SAC with autotune (the last actor update ends with a trunk + tail
-// pair through the final actor: the temperature draw), one or two critic-only iterations behind it, and an opening trunk that reads
-// ring rows itself (narrow observations below the large-batch threshold, wide ones at large batch).
+// Is the period graph built in its pipelined form (see BatchSlot)?  One or two critic-only iterations behind the one with the actor
+// updates, and an opening trunk that reads ring rows itself (narrow observations below the large-batch threshold, wide ones at large batch).
+// does the actor's weight-gradient launch take the split-M route (k_tn64 + k_adam_red: no T2 / T3 support)?  (launch_tn's rule)
+static bool actor_dw_is_tiled64(const sactd3_engine* e) {
+  if (e->B < BIG_BATCH || !e->Gp || e->tune_tn_kt) return false;
+  const int tiles = ((e->nh + TN64_N - 1) / TN64_N) * ((HID + TN64_K - 1) / TN64_K) + ((HID + TN64_N - 1) / TN64_N) * ((HID + TN64_K - 1) / TN64_K)
+                    + ((HID + TN64_N - 1) / TN64_N) * ((e->La.ld1 + TN64_K - 1) / TN64_K);
+  return tiles >= e->tune_tn64_min;
+}
 static bool period_is_pipelined(const sactd3_engine* e) {
   const sactd3_config& c = e->cfg;
-  return !c.prefer_td3_over_sac && c.autotune && c.actor_update_delay >= 1 && c.actor_update_delay <= 2 && opening_trunk_gathers(e);
+  if (c.actor_update_delay < 1 || c.actor_update_delay > 2 || !opening_trunk_gathers(e)) return false;
+  // SAC: needs the temperature draw's trunk + tail pair at the end of the last actor update (autotune);
+  // TD3: the run-ahead through the target actors of the next Polyak updates (T2 / T3 in the k_tn epilogue: no gradient clipping,
+  // no split-M route for the actor's weight gradients)
+  if (c.prefer_td3_over_sac) return c.clip_norm <= 0.f && !actor_dw_is_tiled64(e);
+  return c.autotune != 0;
 }
 // variant (pipelined form only): which batch slot the period's first iteration trains on (0: slot 0, 1: slot 3) -- the other one
 // receives the opening pair of the NEXT period, so consecutive periods alternate (chain_ready).  The pipelined form assumes its own

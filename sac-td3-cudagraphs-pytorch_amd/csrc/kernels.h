@@ -1220,6 +1220,7 @@ struct AdamRedArgs {
   const float* Gp; int S; int nets; long g_ns;           // slabs [S][nets][g_ns]
   float* G;                                              // gradient arena (always written)
   int apply; float* P; float* Mo; float* Vo; float* T; float tau;
+  float* T2; float* T3;                                  // optional: the target one / two further Polyak steps ahead (see TnArgs)
   const float* adam; float b1, b2, eps;
   AdamRedVec vec[5]; int nvec;                           // 256-wide vectors finalised from row-block partials (nblk blocks each)
   const float* part; int pstride;
@@ -1236,7 +1237,15 @@ __device__ __forceinline__ void adam_red_commit(const AdamRedArgs& a, long off, 
     w.x -= step * (m.x / (sqrtf(v.x) / sq2 + a.eps)); w.y -= step * (m.y / (sqrtf(v.y) / sq2 + a.eps));
     w.z -= step * (m.z / (sqrtf(v.z) / sq2 + a.eps)); w.w -= step * (m.w / (sqrtf(v.w) / sq2 + a.eps));
     st4(a.Mo + off, m); st4(a.Vo + off, v); st4(a.P + off, w);
-    if (a.T) st4(a.T + off, tt + (w - tt) * a.tau);
+    if (a.T) {
+      const float4 t1 = tt + (w - tt) * a.tau;
+      st4(a.T + off, t1);
+      if (a.T2) {
+        const float4 t2 = t1 + (w - t1) * a.tau;
+        st4(a.T2 + off, t2);
+        if (a.T3) st4(a.T3 + off, t2 + (w - t2) * a.tau);
+      }
+    }
   }
 }
 // The "tail" blocks of a gradient finalisation: block `rel` < 4 nvec = one quarter of a 256-wide vector gradient (float4 column
@@ -1324,7 +1333,10 @@ struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16
   float* G; long g_ns;                   // gradient arena (always written; net stride g_ns)
   // optimiser step fused into the epilogue (torch.optim.Adam, agents/agent.py:236,286), optionally with the Polyak
   // update of the same element (agents/agent.py:328).  apply == 0: gradients only (clip_grad_norm_ path).
-  int apply; float* P; float* Mo; float* Vo; float* T; float tau;
+  // T2 / T3 (TD3 period graphs): the parameters do not change again before the next two Polyak updates of this target, so what
+  // those will produce -- t2 = t1 + (w - t1) tau, t3 = t2 + (w - t2) tau, the very expressions they evaluate -- is written to two
+  // more arenas now: the next-action passes of the following iterations run ahead through them (engine.hip: enqueue_update_actor)
+  int apply; float* P; float* Mo; float* Vo; float* T; float tau; float* T2; float* T3;
   const float* adam;                     // [0] lr / (1 - b1^t), [1] sqrt(1 - b2^t), published by the first kernel of the update
   float b1, b2, eps;
   const float* part; int pstride; const float* part_s;   // pstride = partial blocks allocated per net
@@ -1352,7 +1364,15 @@ __device__ __forceinline__ void adam_commit(const TnArgs& p, long off, float g, 
     const float v = s.v * p.b2 + g * g * (1.0f - p.b2);
     const float w = s.w - step * (m / (sqrtf(v) / sq2 + p.eps));
     p.Mo[off] = m; p.Vo[off] = v; p.P[off] = w;
-    if (p.T) p.T[off] = s.t + (w - s.t) * p.tau;
+    if (p.T) {
+      const float t1 = s.t + (w - s.t) * p.tau;
+      p.T[off] = t1;
+      if (p.T2) {
+        const float t2 = t1 + (w - t1) * p.tau;
+        p.T2[off] = t2;
+        if (p.T3) p.T3[off] = t2 + (w - t2) * p.tau;
+      }
+    }
   }
 }
 

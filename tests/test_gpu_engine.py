@@ -682,12 +682,14 @@ def test_period_graph_equals_single_iterations(algo, env, B):
             # + tail: 2 nodes at narrow observations, 3 at wide ones) run ahead in the first iteration's last actor-trunk / tail launches,
             # and so does the opening pair of the NEXT period -- so a period graph holds no opening nodes at all; a 2- / 3-node opening
             # graph runs only when no precomputed pair is there (the first period, or after any state change in between)
+            # TD3: the same, through the target actors of the NEXT Polyak updates (written ahead by the last actor update's Adam epilogue);
+            # it has no temperature pair to ride in, so the run-ahead is a trunk + tail pair of its own at the end of the first iteration
             c0, c1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
+            opening = 3 if env == "humanoid" else 2
             if algo == "sac":
-                opening = 3 if env == "humanoid" else 2
                 assert eng.graph_kernel_count(4) == c1 - 1 + 2 * (c0 - opening) - opening and eng.graph_kernel_count(5) == opening
             else:
-                assert eng.graph_kernel_count(4) == c0 * 2 + c1 and eng.graph_kernel_count(5) == 0
+                assert eng.graph_kernel_count(4) == c1 + 2 * (c0 - opening) and eng.graph_kernel_count(5) == opening
         else:
             for i in range(1, 11):
                 eng.step(i % 3 == 0)
@@ -704,7 +706,8 @@ def test_period_graph_equals_single_iterations(algo, env, B):
         assert eng.run_iterations(0, 7) == 7 and eng.get_adam_state(_lib.CRITICS)[2] == 7
 
 
-@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("sac", "humanoid", 1024), ("sac", "halfcheetah", 64), ("td3", "halfcheetah", 256)])
+@pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("sac", "humanoid", 1024), ("sac", "halfcheetah", 64), ("td3", "halfcheetah", 256),
+                                        ("td3", "humanoid", 1024), ("td3", "hopper", 64)])
 def test_chained_periods_with_state_changes_in_between_equal_single_iterations(algo, env, B):
     """A SAC period graph leaves the NEXT period's opening pair (sample, gather, next-action pass, first policy pass) precomputed;
     that is only valid while nothing it depends on changes.  Interleave periods with everything a caller may do between two of them
@@ -739,7 +742,7 @@ def test_chained_periods_with_state_changes_in_between_equal_single_iterations(a
         res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR_TARGET),
                     eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"], eng.read_noise(_lib.SITE_CRITIC), acted,
                     eng.get_adam_state(_lib.CRITICS)[2], eng.get_adam_state(_lib.ACTOR)[2], np.array(list(eng.read_metrics().values()))))
-        if mode == "period" and algo == "sac":
+        if mode == "period":
             assert eng.graph_kernel_count(5) > 0                # the opening graph exists: the chained form was in use
     for x, y in zip(*res):
         assert np.array_equal(x, y)
