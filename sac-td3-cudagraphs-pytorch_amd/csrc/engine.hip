@@ -756,16 +756,24 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, tk));
   }
   e->node_role = "critic/loss+backward";
+  bool fused_tail_nn = false;
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
     t.rew = S.rew; t.done = S.done; t.logp_next = S.logp_n; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.bcq = c.bcq_style_targ_mix; t.gamma = c.gamma;
     t.qt = e->qt; t.y = e->y; t.q = e->q; t.dz2 = e->c_dz2; t.part = e->part; t.part_s = e->part_s; t.pstride = e->nblk4;
-    if (e->tune_rows4 & 1) LAUNCH("k_critic_tail<4>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<4>, dim3(e->nblk4, 2), dim3(64), t);
+    fused_tail_nn = B < BIG_BATCH && !(e->tune_rows4 & 2048);
+    if (fused_tail_nn) {   // the tail AND dh1 = dz2 W2 in one launch (k_ctail_nn): 16-row blocks x 32-column tiles
+      CtailNn f{};
+      f.c = t; f.c.pstride = e->nblk4; f.Wt = e->Pc + e->Lc.W2; f.ldw = HID; f.dX = e->c_dh1;
+      f.xr = pick_xr(e, e->nblk, HID / 32, 4.0 * 3 * B * HID, 4.0 * HID * HID);
+      LAUNCH("k_ctail_nn<2>", 2.0 * 4 * B * (double)HID + 2.0 * 2 * (double)B * HID * HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B) + 4.0 * 2 * ((double)HID * HID + (double)B * HID),
+             k_ctail_nn<2>, dim3((unsigned)(e->nblk * (HID / 32)), 1, 2), dim3(256), f);
+    } else if (e->tune_rows4 & 1) LAUNCH("k_critic_tail<4>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<4>, dim3(e->nblk4, 2), dim3(64), t);
     else LAUNCH("k_critic_tail<16>", 2.0 * 4 * B * (double)HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B), k_critic_tail<16>, dim3(e->nblk, 2), dim3(256), t);
   }
-  {  // dh1 = dz2 W2
+  if (!fused_tail_nn) {  // dh1 = dz2 W2
     NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
@@ -784,7 +792,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     TnArgs g{};
     g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
     g.pr[0] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
-    const int nb_tail = (e->tune_rows4 & 1) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
+    const int nb_tail = (!fused_tail_nn && (e->tune_rows4 & 1)) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
     if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[0], 1, e->Lc.be2, nb_tail); }
     tn_fin(g.pr[0], 2, e->Lc.Wh, nb_tail); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = nb_tail;
     g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, S.X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);

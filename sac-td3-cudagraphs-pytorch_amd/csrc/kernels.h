@@ -2250,6 +2250,146 @@ __global__ __launch_bounds__(16 * RPB) void k_critic_tail(CriticTail p) {
   STAMP(3);
 }
 
+// k_critic_tail + k_nn in ONE launch (B < 1024): a block = 16 batch rows x 16 NT columns of dh1 = dz2 W2.  Every block redoes the
+// tail arithmetic of its 16 rows (256 threads = 16 rows x 16 threads, exactly k_critic_tail<16>'s layout: three LayerNorms, three
+// head dot products, the Bellman target, the LayerNorm backward -- a few hundred cycles), parks the dz2 rows in LDS as the A operand
+// and multiplies them with its W2 column tiles (requested with the first batch of loads, as k_nn does).  What the tail kernel
+// stored once per row block is spread over the row block's column-tile blocks: each stores ITS 16 NT columns of dz2 and of the
+// three column partials; the scalars (q, target q, y, loss partials) come from the column-tile-0 block.  One graph node and one
+// cold round trip fewer per critic update; the price is 57 KB of tail operands per block instead of 16 KB of dz2 rows.
+struct CtailNn { CriticTail c; const float* Wt; int ldw; float* dX; int xr; };
+template <int NT>
+__global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
+  const CriticTail& p = a.c;
+  constexpr int CB = 16 * NT;                               // columns per block
+  __shared__ __attribute__((aligned(16))) float Dz[16 * AS];
+  __shared__ __attribute__((aligned(16))) float cs[3 * 16 * CB];
+  __shared__ __attribute__((aligned(16))) float red[NT * 4 * 64 * 4];
+  __shared__ float sc[16][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, row = t >> 4, sub = t & 15, net = blockIdx.z;
+  const int r = lane & 15, kq = lane >> 4;
+  int tm, tk;
+  xcd_tile(blockIdx.x, (p.B + 15) >> 4, HID / CB, a.xr, tm, tk);
+  const int b = tm * 16 + row, bc = min(b, p.B - 1), c_lo = tk * CB;
+  const bool valid = b < p.B;
+  const float* Pn = p.P + net * p.p_ns;
+  // ---- every load: the tail's rows and parameters, then this block's W2 fragments (k_nn's B operand)
+  const Row16 zt0 = row_ld(p.z2t + (long)bc * HID, sub), zt1 = row_ld(p.z2t + ((long)p.B + bc) * HID, sub);
+  const Row16 zo = row_ld(p.z2 + ((long)net * p.B + bc) * HID, sub);
+  const Row16 wt0 = row_ld(p.PT + p.L.Wh, sub), wt1 = row_ld(p.PT + p.p_ns + p.L.Wh, sub), wo = row_ld(Pn + p.L.Wh, sub);
+  Row16 gt0, bt0, gt1, bt1, go, bo;
+  if (p.ln) {
+    gt0 = row_ld(p.PT + p.L.g2, sub); bt0 = row_ld(p.PT + p.L.be2, sub);
+    gt1 = row_ld(p.PT + p.p_ns + p.L.g2, sub); bt1 = row_ld(p.PT + p.p_ns + p.L.be2, sub);
+    go = row_ld(Pn + p.L.g2, sub); bo = row_ld(Pn + p.L.be2, sub);
+  }
+  const float bht0 = p.PT[p.L.bh], bht1 = p.PT[p.p_ns + p.L.bh], bho = Pn[p.L.bh];
+  const float rw = p.rew[bc], dn = p.done[bc];
+  const float alpha = p.sac ? expf(*p.log_alpha) : 0.f;
+  const float lpn = p.sac ? p.logp_next[bc] : 0.f;
+  const int nb = 64 * wave + 4 * kq;
+  float4 bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float* Wc = a.Wt + net * p.p_ns + (long)nb * a.ldw + c_lo + 16 * nt + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* w = Wc + (long)(16 * c) * a.ldw;
+      bv[nt][c] = make_float4(w[0], w[a.ldw], w[2 * (long)a.ldw], w[3 * (long)a.ldw]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- the tail (k_critic_tail's arithmetic, agents/agent.py:208-233)
+  Row16 xh, y, h; float rs;
+  ln_fwd(zt0, gt0, bt0, p.ln, xh, y, rs);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qt0 = row16_sum(row_dot(h, wt0)) + bht0;
+  ln_fwd(zt1, gt1, bt1, p.ln, xh, y, rs);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qt1 = row16_sum(row_dot(h, wt1)) + bht1;
+  const float qmin = fminf(qt0, qt1);
+  float qp = p.bcq ? 0.75f * qmin + 0.25f * fmaxf(qt0, qt1) : qmin;
+  if (p.sac) qp -= alpha * lpn;
+  const float yv = rw + (1.0f - dn) * p.gamma * qp;
+  float rstd;
+  ln_fwd(zo, go, bo, p.ln, xh, y, rstd);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h.v[q] = relu4(y.v[q]);
+  const float qv = row16_sum(row_dot(h, wo)) + bho;
+  const float err = valid ? qv - yv : 0.f;
+  const float dq = 2.0f * err / (float)p.B;
+  Row16 dy, vals[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(wo.v[q] * dq, y.v[q]);
+  const Row16 dz = ln_bwd(dy, xh, rstd, go, p.ln);          // (rows beyond the batch: err = 0 -> all zeros)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; vals[2].v[q] = h.v[q] * dq; }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { PIN(bv[nt][c].x); PIN(bv[nt][c].y); PIN(bv[nt][c].z); PIN(bv[nt][c].w); }
+  // ---- stores of this block's share: its columns of dz2 and of the three column partials; scalars by the column-tile-0 block
+  row_st(Dz + row * AS, sub, dz);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = 4 * sub + 64 * q;                      // (the thread's float4 of chunk q lies inside one 16-column tile)
+    if (col >= c_lo && col < c_lo + CB) {
+      if (valid) st4(p.dz2 + ((long)net * p.B + b) * HID + col, dz.v[q]);
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) st4(cs + (sl * 16 + row) * CB + (col - c_lo), vals[sl].v[q]);
+    }
+  }
+  if (tk == 0 && sub == 0) {
+    sc[row][0] = dq; sc[row][1] = err * err;
+    if (valid) {
+      p.q[(long)net * p.B + b] = qv;
+      if (net == 0) { p.qt[b] = qt0; p.qt[p.B + b] = qt1; p.y[b] = yv; }
+    }
+  }
+  __syncthreads();
+  const long blk = (long)net * p.pstride + tm;
+  if (t < 3 * CB) {
+    const int sl = t / CB, c = t - sl * CB;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += cs[(sl * 16 + i) * CB + c];
+    p.part[(blk * NSLOT + sl) * HID + c_lo + c] = sum;
+  }
+  if (tk == 0 && t >= 128 && t < 130) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += sc[i][t - 128];
+    p.part_s[blk * 2 + (t - 128)] = sum;
+  }
+  // ---- dh1 tile(s): rows from LDS, W2 fragments from registers, the 256-long reduction split over the 4 waves (k_nn)
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 av = ld4(Dz + r * AS + nb + 16 * c);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[nt], av, bv[nt][c]); }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+  __syncthreads();
+  if (wave < NT) {
+    const float* rr = red + (wave * 4 * 64 + lane) * 4;
+    const float4 x0 = ld4(rr), x1 = ld4(rr + 256), x2 = ld4(rr + 512), x3 = ld4(rr + 768);
+    const float o[4] = {(x0.x + x1.x) + (x2.x + x3.x), (x0.y + x1.y) + (x2.y + x3.y), (x0.z + x1.z) + (x2.z + x3.z), (x0.w + x1.w) + (x2.w + x3.w)};
+    const int col = c_lo + 16 * wave + (lane & 15);
+    float* x = a.dX + (long)net * p.B * HID;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int orow = tm * 16 + 4 * (lane >> 4) + i;
+      if (orow < p.B) x[(long)orow * HID + col] = o[i];
+    }
+  }
+}
+
 struct ActorQTail {
   const float* z2c;                      // [nq][B][HID]
   const float* P; long p_ns; NetLayout L;// online critics
