@@ -855,13 +855,25 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 1, nq, &g, tk));
   }
   e->node_role = (j & 1) ? "actor1/loss+backward" : "actor0/loss+backward";
+  const bool fused_qtail_nn = B < BIG_BATCH && !(e->tune_rows4 & 2048);
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
     t.B = B; t.ln = ln; t.sac = !td3; t.q = e->q_pi; t.dz2 = e->c_dz2; t.part_s = e->part_sa;
-    LAUNCH("k_actorq_tail<4>", 2.0 * nq * B * (double)HID, 4.0 * nq * (2.0 * BH + 4.0 * HID + 2.0 * B), k_actorq_tail<4>, dim3(e->nblk4), dim3(64), t);
+    if (fused_qtail_nn) {   // the tail AND dh1_i = dz2_i W2_i in one launch (k_qtail_nn): loss partials per 16-row block
+      QtailNn f{};
+      f.c = t; f.Wt = e->Pc + e->Lc.W2; f.ldw = HID; f.dX = e->c_dh1;
+      const double fl = 2.0 * nq * B * (double)HID + 2.0 * nq * (double)B * HID * HID, by = 4.0 * nq * (2.0 * BH + 4.0 * HID + 2.0 * B) + 4.0 * nq * ((double)HID * HID + (double)B * HID);
+      if (nq == 2) {
+        f.xr = pick_xr(e, e->nblk, HID / 32, 4.0 * 2 * B * HID, 4.0 * HID * HID);
+        LAUNCH("k_qtail_nn<2>", fl, by, k_qtail_nn<2>, dim3((unsigned)(e->nblk * (HID / 32)), 1, 2), dim3(256), f);
+      } else {
+        f.xr = pick_xr(e, e->nblk, HID / 16, 4.0 * B * HID, 4.0 * HID * HID);
+        LAUNCH("k_qtail_nn<1>", fl, by, k_qtail_nn<1>, dim3((unsigned)(e->nblk * (HID / 16)), 1, 1), dim3(256), f);
+      }
+    } else LAUNCH("k_actorq_tail<4>", 2.0 * nq * B * (double)HID, 4.0 * nq * (2.0 * BH + 4.0 * HID + 2.0 * B), k_actorq_tail<4>, dim3(e->nblk4), dim3(64), t);
   }
-  {
+  if (!fused_qtail_nn) {
     NnArgs g{};
     g.dY = e->c_dz2; g.dy_ns = BH; g.Wt = e->Pc + e->Lc.W2; g.ldw = HID; g.p_ns = e->Lc.size; g.k_off = 0;
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;

@@ -2454,6 +2454,115 @@ __global__ __launch_bounds__(16 * RPB) void k_actorq_tail(ActorQTail p) {
   }
 }
 
+// k_actorq_tail + k_nn in ONE launch (B < 1024), as k_ctail_nn: a block = 16 batch rows x 16 NT columns of dh1_i = dz2_i W2_i of
+// critic i = blockIdx.z.  Every block evaluates BOTH critics' heads on its rows (the min decides which critic a row's gradient
+// flows through), keeps its own critic's dz2 rows in LDS as the A operand; nothing downstream reads dz2 itself in the actor
+// update, so it is not stored.  Q(s, pi(s)) and the loss partial come from the column-tile-0 blocks.
+struct QtailNn { ActorQTail c; const float* Wt; int ldw; float* dX; int xr; };
+template <int NT>
+__global__ __launch_bounds__(256) void k_qtail_nn(QtailNn a) {
+  const ActorQTail& p = a.c;
+  constexpr int CB = 16 * NT;
+  __shared__ __attribute__((aligned(16))) float Dz[16 * AS];
+  __shared__ __attribute__((aligned(16))) float red[NT * 4 * 64 * 4];
+  __shared__ float sc[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, row = t >> 4, sub = t & 15, net = blockIdx.z;
+  const int r = lane & 15, kq = lane >> 4;
+  int tm, tk;
+  xcd_tile(blockIdx.x, (p.B + 15) >> 4, HID / CB, a.xr, tm, tk);
+  const int b = tm * 16 + row, bc = min(b, p.B - 1), c_lo = tk * CB;
+  const bool valid = b < p.B;
+  const int nq = p.sac ? 2 : 1;
+  Row16 z[2], w[2], g[2], be[2], xh[2], y[2];
+  float rstd[2], qv[2] = {0.f, 0.f}, bh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i < nq) {
+      const float* Pi = p.P + i * p.p_ns;
+      z[i] = row_ld(p.z2c + ((long)i * p.B + bc) * HID, sub);
+      w[i] = row_ld(Pi + p.L.Wh, sub);
+      if (p.ln) { g[i] = row_ld(Pi + p.L.g2, sub); be[i] = row_ld(Pi + p.L.be2, sub); }
+      bh[i] = Pi[p.L.bh];
+    }
+  const float alpha = p.sac ? expf(*p.log_alpha) : 0.f;
+  const float lpv = p.sac ? p.logp[bc] : 0.f;
+  const int nb = 64 * wave + 4 * kq;
+  float4 bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float* Wc = a.Wt + net * p.p_ns + (long)nb * a.ldw + c_lo + 16 * nt + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* wp = Wc + (long)(16 * c) * a.ldw;
+      bv[nt][c] = make_float4(wp[0], wp[a.ldw], wp[2 * (long)a.ldw], wp[3 * (long)a.ldw]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i < nq) {
+      ln_fwd(z[i], g[i], be[i], p.ln, xh[i], y[i], rstd[i]);
+      Row16 h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h.v[q] = relu4(y[i].v[q]);
+      qv[i] = row16_sum(row_dot(h, w[i])) + bh[i];
+    }
+  const bool first = p.sac ? (qv[0] <= qv[1]) : true;
+  const float loss = p.sac ? (alpha * lpv - (first ? qv[0] : qv[1])) : -qv[0];
+  const float invB = 1.0f / (float)p.B;
+  // this block's critic: dq = -1/B where it is the minimum, else 0 (agents/agent.py:272-281); rows beyond the batch: 0
+  const bool mine = valid && ((net == 0) == first);
+  const float dq = mine ? -invB : 0.f;
+  Row16 dy;
+  const Row16& wn = net == 0 ? w[0] : w[1];
+  const Row16& yn = net == 0 ? y[0] : y[1];
+  const Row16& xn = net == 0 ? xh[0] : xh[1];
+  const Row16& gn = net == 0 ? g[0] : g[1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(wn.v[q] * dq, yn.v[q]);
+  const Row16 dz = ln_bwd(dy, xn, net == 0 ? rstd[0] : rstd[1], gn, p.ln);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { PIN(bv[nt][c].x); PIN(bv[nt][c].y); PIN(bv[nt][c].z); PIN(bv[nt][c].w); }
+  row_st(Dz + row * AS, sub, dz);
+  if (tk == 0 && sub == 0) {
+    if (valid) p.q[(long)net * p.B + b] = net == 0 ? qv[0] : qv[1];
+    if (net == 0) sc[row] = valid ? loss : 0.f;
+  }
+  __syncthreads();
+  if (tk == 0 && net == 0 && t == 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += sc[i];
+    p.part_s[tm * 2 + 1] = sum;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 av = ld4(Dz + r * AS + nb + 16 * c);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[nt], av, bv[nt][c]); }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+  __syncthreads();
+  if (wave < NT) {
+    const float* rr = red + (wave * 4 * 64 + lane) * 4;
+    const float4 x0 = ld4(rr), x1 = ld4(rr + 256), x2 = ld4(rr + 512), x3 = ld4(rr + 768);
+    const float o[4] = {(x0.x + x1.x) + (x2.x + x3.x), (x0.y + x1.y) + (x2.y + x3.y), (x0.z + x1.z) + (x2.z + x3.z), (x0.w + x1.w) + (x2.w + x3.w)};
+    const int col = c_lo + 16 * wave + (lane & 15);
+    float* x = a.dX + (long)net * p.B * HID;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int orow = tm * 16 + 4 * (lane >> 4) + i;
+      if (orow < p.B) x[(long)orow * HID + col] = o[i];
+    }
+  }
+}
+
 struct LnBwd {               // dz = LNbwd(relu'(.) * dh) for hidden layer 1; optional (dgamma, dbeta) partials
   const float* dh; const float* xh; const float* h; const float* rstd;   // [nets][B][HID] x3, [nets][B]
   const float* gamma; long p_ns;
