@@ -889,18 +889,27 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     LAUNCH("k_ln_bwd<16>.dQ/da", 2.0 * nq * B * (double)HID * e->a, 4.0 * nq * (4.0 * BH + B + HID + (double)HID * e->a + (double)B * e->a),
            k_ln_bwd<16>, dim3(e->nblk, nq), dim3(256), l);
   }
+  bool fused_head_nn = false;
   {
     ActorHeadBwd h{};
     h.dA = e->dA; h.dA_ns = (long)B * e->a4; h.ldA = e->a4; h.nq = nq; h.tg = e->a_tg; h.a4 = e->a4; h.eps = e->eps[sb_a];
     h.log_alpha = e->la; h.scale = e->scale; h.P = e->Pa; h.L = e->La; h.xh2 = e->a_xh2; h.rstd2 = e->a_rs2; h.h2 = e->a_h2;
     h.B = B; h.a = e->a; h.ln = ln; h.sac = !td3; h.du = e->a_du; h.ldu = e->ldu; h.dz2 = e->a_dz2;
     h.part = e->part;
-    if (small_head) LAUNCH("k_actor_head_bwd_s<4>", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
+    fused_head_nn = small_head && B < BIG_BATCH && !(e->tune_rows4 & 2048);
+    if (fused_head_nn) {   // the head backward AND dh1 = dz2 W2 in one launch (k_headbwd_nn): column partials per 16-row block
+      HeadBwdNn f{};
+      f.c = h; f.Wt = e->Pa + e->La.W2; f.ldw = HID; f.dX = e->a_dh1;
+      f.xr = pick_xr(e, e->nblk, HID / 16, 4.0 * 2 * B * HID, 4.0 * HID * HID);
+      LAUNCH("k_headbwd_nn", 2.0 * B * (double)HID * e->nh + 2.0 * (double)B * HID * HID,
+             4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)) + 4.0 * ((double)HID * HID + (double)B * HID),
+             k_headbwd_nn, dim3((unsigned)(e->nblk * (HID / 16))), dim3(256), f);
+    } else if (small_head) LAUNCH("k_actor_head_bwd_s<4>", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
                            k_actor_head_bwd_s<4>, dim3(e->nblk4), dim3(64), h);
     else LAUNCH("k_actor_head_bwd", 2.0 * B * (double)HID * e->nh, 4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)),
                 k_actor_head_bwd, dim3(e->nblk), dim3(256), h);
   }
-  {
+  if (!fused_head_nn) {
     NnArgs g{};
     g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, "k_nn.dh1", g, 1));
@@ -917,7 +926,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
     g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
     g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
-    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, small_head ? e->nblk4 : e->nblk); tn_fin(g.pr[1], 1, e->La.be2, small_head ? e->nblk4 : e->nblk); }
+    const int nb_head = (small_head && !fused_head_nn) ? e->nblk4 : e->nblk;      // row blocks that wrote the head backward's column partials
+    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, nb_head); tn_fin(g.pr[1], 1, e->La.be2, nb_head); }
     g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, SX, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
     if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;

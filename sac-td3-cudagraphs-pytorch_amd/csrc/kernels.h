@@ -2821,6 +2821,127 @@ __global__ __launch_bounds__(16 * RPB) void k_actor_head_bwd_s(ActorHeadBwd p) {
   block_colsum<RPB>(cs, vals, 2, row, sub, p.part + (long)blockIdx.x * NSLOT * HID);
 }
 
+// k_actor_head_bwd_s + k_nn in ONE launch (narrow heads, B < 1024), as k_ctail_nn: a block = 16 batch rows x 16 columns of the
+// actor's dh1 = dz2 W2.  Every block redoes the head backward of its 16 rows (k_actor_head_bwd_s's arithmetic: lane n of a row
+// computes du[n], DPP row broadcast, nh FMAs per column, LayerNorm backward), keeps the dz2 rows in LDS as the A operand, and
+// stores ITS 16 columns of dz2 and of the two column partials; du comes from the column-tile-0 block.
+struct HeadBwdNn { ActorHeadBwd c; const float* Wt; int ldw; float* dX; int xr; };
+__global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
+  const ActorHeadBwd& p = a.c;
+  constexpr int CB = 16;
+  __shared__ __attribute__((aligned(16))) float Dz[16 * AS];
+  __shared__ __attribute__((aligned(16))) float cs[2 * 16 * CB];
+  __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, row = t >> 4, sub = t & 15;
+  const int r = lane & 15, kq = lane >> 4;
+  int tm, tk;
+  xcd_tile(blockIdx.x, (p.B + 15) >> 4, HID / CB, a.xr, tm, tk);
+  const int b = tm * 16 + row, bc = min(b, p.B - 1), c_lo = tk * CB;
+  const bool valid = b < p.B;
+  const int nh = p.L.nh;                         // <= 8, and a <= 8
+  const float* Wh = p.P + p.L.Wh;
+  // ---- loads first (k_actor_head_bwd_s), then this block's W2 fragments (k_nn's B operand)
+  const long ro = (long)bc * HID;
+  const Row16 hh = row_ld(p.h2 + ro, sub), xh = row_ld(p.xh2 + ro, sub);
+  Row16 g;
+  if (p.ln) g = row_ld(p.P + p.L.g2, sub);
+  const float rstd = p.ln ? p.rstd2[bc] : 1.f;
+  Row16 w[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) w[n] = row_ld(Wh + (long)min(n, nh - 1) * HID, sub);   // unconditional, row clamped
+  const bool second = sub >= p.a;
+  const int j0 = min(second ? sub - p.a : sub, p.a - 1);
+  const float* tgr = p.tg + (long)bc * 4 * p.a4;
+  float la = p.sac ? *p.log_alpha : 0.f;
+  float o_dA = p.dA[(long)bc * p.ldA + j0], o_dA1 = p.nq == 2 ? p.dA[p.dA_ns + (long)bc * p.ldA + j0] : 0.f;
+  float o_sc = p.scale[j0], o_t0 = tgr[j0];
+  float o_t1 = 0.f, o_t2 = 0.f, o_e = 0.f;
+  if (p.sac) { o_t1 = tgr[p.a4 + j0]; o_t2 = tgr[2 * p.a4 + j0]; o_e = p.eps[(long)bc * p.a + j0]; }
+  const int nb = 64 * wave + 4 * kq;
+  float4 bv[4];
+  {
+    const float* Wc = a.Wt + (long)nb * a.ldw + c_lo + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* wp = Wc + (long)(16 * c) * a.ldw;
+      bv[c] = make_float4(wp[0], wp[a.ldw], wp[2 * (long)a.ldw], wp[3 * (long)a.ldw]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
+  const float dlogp = p.sac ? expf(la) / (float)p.B : 0.f;
+  float d;                                        // du[sub]
+  {
+    const float dAj = o_dA + o_dA1, sc = o_sc;
+    float g_mean, g_raw = 0.f;
+    if (p.sac) {
+      const float tt = o_t0, sd = o_t1, yt = o_t2;
+      const float omy2 = 1.0f - yt * yt;
+      const float g0 = dAj * sc * omy2 + dlogp * (2.0f * sc * yt * omy2) / (sc * omy2 + 1e-6f);
+      g_mean = g0;
+      g_raw = (g0 * o_e * sd - dlogp) * 3.5f * (1.0f - tt * tt);
+    } else {
+      g_mean = dAj * sc * (1.0f - o_t0 * o_t0);
+    }
+    d = second ? g_raw : g_mean;
+    if (!valid || sub >= nh) d = 0.f;
+  }
+  Row16 dh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dh.v[q] = f4(0.f);
+  auto add_n = [&](float dn, const Row16& wn) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dh.v[q] = dh.v[q] + wn.v[q] * dn;
+  };
+  row_pin(w[0]); add_n(dpp_mov<0x150>(d), w[0]);           // row_newbcast:n = lane n of every 16-lane row to all of its lanes
+  row_pin(w[1]); add_n(dpp_mov<0x151>(d), w[1]);
+  row_pin(w[2]); add_n(dpp_mov<0x152>(d), w[2]);
+  row_pin(w[3]); add_n(dpp_mov<0x153>(d), w[3]);
+  row_pin(w[4]); add_n(dpp_mov<0x154>(d), w[4]);
+  row_pin(w[5]); add_n(dpp_mov<0x155>(d), w[5]);
+  row_pin(w[6]); add_n(dpp_mov<0x156>(d), w[6]);
+  row_pin(w[7]); add_n(dpp_mov<0x157>(d), w[7]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { PIN(bv[c].x); PIN(bv[c].y); PIN(bv[c].z); PIN(bv[c].w); }
+  if (tk == 0 && valid && sub < nh) p.du[(long)b * p.ldu + sub] = d;
+  Row16 dy, vals[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dy.v[q] = gate4(dh.v[q], hh.v[q]);
+  const Row16 dz = ln_bwd(dy, xh, rstd, g, p.ln);           // (rows beyond the batch: d = 0 -> all zeros)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { vals[0].v[q] = dy.v[q] * xh.v[q]; vals[1].v[q] = dy.v[q]; }
+  row_st(Dz + row * AS, sub, dz);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = 4 * sub + 64 * q;
+    if (col >= c_lo && col < c_lo + CB) {
+      if (valid) st4(p.dz2 + (long)b * HID + col, dz.v[q]);
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) st4(cs + (sl * 16 + row) * CB + (col - c_lo), vals[sl].v[q]);
+    }
+  }
+  __syncthreads();
+  if (t < 2 * CB) {
+    const int sl = t / CB, c = t - sl * CB;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += cs[(sl * 16 + i) * CB + c];
+    p.part[((long)tm * NSLOT + sl) * HID + c_lo + c] = sum;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { const float4 av = ld4(Dz + r * AS + nb + 16 * c); MFMA4(acc, av, bv[c]); }
+  acc = splitk_reduce(red, acc, wave, lane);
+  const int col = c_lo + (lane & 15);
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int orow = tm * 16 + 4 * (lane >> 4) + i;
+      if (orow < p.B) a.dX[(long)orow * HID + col] = acc[i];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ optimiser
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; long n;   // n multiple of 4
