@@ -109,6 +109,7 @@ struct sactd3_engine {
   float* eps[SACTD3_NUM_SITES] = {};
   float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
+  float *a_ps = nullptr, *c_ps = nullptr;     // row-sum partials of the folded layer-1 LayerNorm backward (TnProb::fold): [nets][B][PS_W]
   float* a_z2n = nullptr;        // layer-2 output of the s' pass when the pi(s) pass shares its launch
   float* ah_z1[4] = {}; float* ah_z2[4] = {};   // layer outputs of the passes that run ahead (pipelined period, see BatchSlot)
   // Batch slots.  Slot 0 is THE batch slot (X, Xn, rew, done, idx, logp_n, eps of the critic site above).  A pipelined period graph
@@ -756,7 +757,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     RCCHK(enqueue_trunk(e, s, e->ldc, e->o + e->a, B, e->Lc, e->Lc.size, 2, 2, g, tk));
   }
   e->node_role = "critic/loss+backward";
-  bool fused_tail_nn = false;
+  bool fused_tail_nn = false, fold_ln1 = false;
   {
     CriticTail t{};
     t.z2t = e->t_z2; t.z2 = e->c_z2; t.PT = e->Tc; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc;
@@ -767,6 +768,8 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     if (fused_tail_nn) {   // the tail AND dh1 = dz2 W2 in one launch (k_ctail_nn): 16-row blocks x 32-column tiles
       CtailNn f{};
       f.c = t; f.c.pstride = e->nblk4; f.Wt = e->Pc + e->Lc.W2; f.ldw = HID; f.dX = e->c_dh1;
+      fold_ln1 = !(e->tune_rows4 & 4096);   // layer 1's LayerNorm backward inside the weight-gradient launch (TnProb::fold)
+      f.f.fold = fold_ln1; f.f.ln = ln; f.f.h1 = e->c_h1; f.f.xh1 = e->c_xh1; f.f.g1_off = e->Lc.g1; f.f.ps = e->c_ps; f.f.gsnap = e->c_ps + 2L * B * PS_W;
       f.xr = pick_xr(e, e->nblk, HID / 32, 4.0 * 3 * B * HID, 4.0 * HID * HID);
       LAUNCH("k_ctail_nn<2>", 2.0 * 4 * B * (double)HID + 2.0 * 2 * (double)B * HID * HID, 4.0 * (6.0 * BH + 4.0 * 4 * HID + 8.0 * B) + 4.0 * 2 * ((double)HID * HID + (double)B * HID),
              k_ctail_nn<2>, dim3((unsigned)(e->nblk * (HID / 32)), 1, 2), dim3(256), f);
@@ -779,7 +782,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, "k_nn.dh1", g, 2));
   }
-  {
+  if (!fold_ln1) {
     LnBwd l{};
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = ln;
@@ -791,12 +794,16 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
      //   dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead ; dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
     TnArgs g{};
     g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
-    g.pr[0] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
+    const int i2 = fold_ln1 ? 1 : 0, i1 = 1 - i2;      // the folded layer-1 problem's blocks carry more: they go first
+    g.pr[i2] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
     const int nb_tail = (!fused_tail_nn && (e->tune_rows4 & 1)) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
-    if (ln) { tn_fin(g.pr[0], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[0], 1, e->Lc.be2, nb_tail); }
-    tn_fin(g.pr[0], 2, e->Lc.Wh, nb_tail); g.pr[0].fin_s_off = e->Lc.bh; g.pr[0].fin_s_nblk = nb_tail;
-    g.pr[1] = tn_prob(e->c_dz1, HID, BH, HID, S.X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
-    if (ln) { tn_fin(g.pr[1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[1], 4, e->Lc.be1, nb_ln); }
+    if (ln) { tn_fin(g.pr[i2], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[i2], 1, e->Lc.be2, nb_tail); }
+    tn_fin(g.pr[i2], 2, e->Lc.Wh, nb_tail); g.pr[i2].fin_s_off = e->Lc.bh; g.pr[i2].fin_s_nblk = nb_tail;
+    g.pr[i1] = tn_prob(fold_ln1 ? e->c_dh1 : e->c_dz1, HID, BH, HID, S.X, e->ldc, 0, e->o + e->a, e->Lc.W1, e->Lc.ld1, e->Lc.b1);
+    if (fold_ln1) {
+      TnProb& q = g.pr[i1];
+      q.fold = 1; q.f_ln = ln; q.f_g_off = e->Lc.g1; q.f_be_off = e->Lc.be1; q.f_xh = e->c_xh1; q.f_rstd = e->c_rs1; q.f_ps = e->c_ps; q.f_dz = e->c_dz1; q.f_g = e->c_ps + 2L * B * PS_W;
+    } else if (ln) { tn_fin(g.pr[i1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[i1], 4, e->Lc.be1, nb_ln); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
@@ -889,7 +896,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     LAUNCH("k_ln_bwd<16>.dQ/da", 2.0 * nq * B * (double)HID * e->a, 4.0 * nq * (4.0 * BH + B + HID + (double)HID * e->a + (double)B * e->a),
            k_ln_bwd<16>, dim3(e->nblk, nq), dim3(256), l);
   }
-  bool fused_head_nn = false;
+  bool fused_head_nn = false, fold_ln1 = false;
   {
     ActorHeadBwd h{};
     h.dA = e->dA; h.dA_ns = (long)B * e->a4; h.ldA = e->a4; h.nq = nq; h.tg = e->a_tg; h.a4 = e->a4; h.eps = e->eps[sb_a];
@@ -900,6 +907,8 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     if (fused_head_nn) {   // the head backward AND dh1 = dz2 W2 in one launch (k_headbwd_nn): column partials per 16-row block
       HeadBwdNn f{};
       f.c = h; f.Wt = e->Pa + e->La.W2; f.ldw = HID; f.dX = e->a_dh1;
+      fold_ln1 = !(e->tune_rows4 & 4096);   // as the critics' (enqueue_update_qnets)
+      f.f.fold = fold_ln1; f.f.ln = ln; f.f.h1 = e->a_h1; f.f.xh1 = e->a_xh1; f.f.g1_off = e->La.g1; f.f.ps = e->a_ps; f.f.gsnap = e->a_ps + (long)B * PS_W;
       f.xr = pick_xr(e, e->nblk, HID / 16, 4.0 * 2 * B * HID, 4.0 * HID * HID);
       LAUNCH("k_headbwd_nn", 2.0 * B * (double)HID * e->nh + 2.0 * (double)B * HID * HID,
              4.0 * (3.0 * BH + (double)e->nh * HID + (double)B * (nq * e->a + 4 * e->a + e->nh)) + 4.0 * ((double)HID * HID + (double)B * HID),
@@ -914,7 +923,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.dY = e->a_dz2; g.Wt = e->Pa + e->La.W2; g.ldw = HID; g.k_off = 0; g.dX = e->a_dh1; g.ldx = HID; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, "k_nn.dh1", g, 1));
   }
-  {
+  if (!fold_ln1) {
     LnBwd l{};
     l.dh = e->a_dh1; l.xh = e->a_xh1; l.h = e->a_h1; l.rstd = e->a_rs1; l.gamma = e->Pa + e->La.g1;
     l.B = B; l.ln = ln; l.want_part = ln; l.dz = e->a_dz1; l.part = e->part; l.pstride = e->nblk4;
@@ -924,12 +933,16 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
      //   dWhead = du^T h2, dbhead ; dW2 = dz2^T h1, db2, dgamma2, dbeta2 ; dW1 = dz1^T s, db1, dgamma1, dbeta1
     TnArgs g{};
     g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
-    g.pr[0] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
-    g.pr[1] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
+    const int ih = fold_ln1 ? 1 : 0, i2 = ih + 1, i1 = fold_ln1 ? 0 : 2;   // the folded layer-1 problem's blocks carry more: they go first
+    g.pr[ih] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
+    g.pr[i2] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
     const int nb_head = (small_head && !fused_head_nn) ? e->nblk4 : e->nblk;      // row blocks that wrote the head backward's column partials
-    if (ln) { tn_fin(g.pr[1], 0, e->La.g2, nb_head); tn_fin(g.pr[1], 1, e->La.be2, nb_head); }
-    g.pr[2] = tn_prob(e->a_dz1, HID, 0, HID, SX, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
-    if (ln) { tn_fin(g.pr[2], 3, e->La.g1, e->nblk); tn_fin(g.pr[2], 4, e->La.be1, e->nblk); }
+    if (ln) { tn_fin(g.pr[i2], 0, e->La.g2, nb_head); tn_fin(g.pr[i2], 1, e->La.be2, nb_head); }
+    g.pr[i1] = tn_prob(fold_ln1 ? e->a_dh1 : e->a_dz1, HID, 0, HID, SX, e->ldc, 0, e->o, e->La.W1, e->La.ld1, e->La.b1);
+    if (fold_ln1) {
+      TnProb& q = g.pr[i1];
+      q.fold = 1; q.f_ln = ln; q.f_g_off = e->La.g1; q.f_be_off = e->La.be1; q.f_xh = e->a_xh1; q.f_rstd = e->a_rs1; q.f_ps = e->a_ps; q.f_dz = e->a_dz1; q.f_g = e->a_ps + (long)B * PS_W;
+    } else if (ln) { tn_fin(g.pr[i1], 3, e->La.g1, e->nblk); tn_fin(g.pr[i1], 4, e->La.be1, e->nblk); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = clip ? nullptr : polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_a;
     if (td3 && g.T && (ahead > 0 || chain_slot >= 0)) { g.T2 = e->Ta2; g.T3 = e->Ta3; }   // the actor target of the next two Polyak updates, now
@@ -1297,6 +1310,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
     RCCHK(dalloc(e, &S.logp_n, B)); RCCHK(dalloc(e, &S.eps_c, std::max<size_t>(B, e->maxn) * e->a)); RCCHK(dalloc(e, &S.idx, B));
   }
   RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
+  RCCHK(dalloc(e, &e->a_ps, (long)B * PS_W + HID)); RCCHK(dalloc(e, &e->c_ps, 2L * B * PS_W + 2 * HID));   // (+ the gamma1 snapshot behind them)
   RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_xh1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_rs1, 2 * B));
   RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));
   RCCHK(dalloc(e, &e->t_z1, 2 * BH)); RCCHK(dalloc(e, &e->t_z2, 2 * BH));

@@ -1327,7 +1327,17 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   int fin_s_off; int fin_s_nblk;         // scalar from part_s[net][blk][0] summed over blk (critic head bias), -1: none
   int tile0;                             // first blockIdx.x of this problem
   int xr;                                // XCD row (n-tile) groups of the tile placement (xcd_tile), 0 = row-major numbering
+  // fold != 0: dY holds dy = relu'(.) dh1 of hidden layer 1 (written by k_ctail_nn / k_headbwd_nn, N = HID) and this problem's
+  // blocks apply the LayerNorm backward to their [M][16] slice on the way into LDS -- the row launch (k_ln_bwd) between the
+  // dh1 GEMM and this one is gone.  What a row needs from its other 240 columns are the two sums over the row; the producer
+  // left them as one partial per 16-column tile (f_ps[net][row][0:16] = sum dy g, [16:32] = sum dy g xhat), summed here in
+  // a fixed order.  The k-tile-0 blocks also own dgamma1 / dbeta1 of their 16 columns (column sums of dy xhat and dy over the
+  // batch) and keep dz1 readable (f_dz).  f_ln == 0: no LayerNorm, dz1 = dy.
+  int fold, f_ln, f_g_off, f_be_off;
+  const float* f_xh; const float* f_rstd; const float* f_ps; float* f_dz;    // [nets][M][HID], [nets][M], [nets][M][32], [nets][M][HID]
+  const float* f_g;                      // [nets][HID]: gamma1 as the producer saw it (the k-tile-0 blocks of THIS launch step the live one)
 };
+constexpr int PS_W = 32;                 // floats per row of the row-sum partials: 16 tiles x 2 sums
 struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
   TnProb pr[3]; int nprob; int M;
   float* G; long g_ns;                   // gradient arena (always written; net stride g_ns)
@@ -1384,6 +1394,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
   __shared__ __attribute__((aligned(16))) float Xs[KT * 256 * YS];
   __shared__ float cred[16 * 17];                        // bias gradient: [16 partial groups][16 columns]
+  __shared__ __attribute__((aligned(16))) float fsum[16 * 4 * 8];   // folded LayerNorm backward: [wave x DPP row][column quad][dgamma 4 | dbeta 4]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if ((int)blockIdx.x >= p.tiles) {                         // (block-uniform) riding blocks
@@ -1415,6 +1426,9 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
   float4 vy[4], vx[KT][4];
+  const bool fold = q.fold != 0, fold_ln = fold && q.f_ln;           // (block-uniform)
+  float4 vxh[4], vp1[4], vp2[4], gq = f4(1.f), cg = f4(0.f), cb = f4(0.f);
+  float vrs[4];
   auto fetch = [&](int mb) {                      // raw loads; masked when the slab is parked in LDS, a stage later (see ld4_raw)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1423,9 +1437,17 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       vy[u] = ld4_raw(dYn + mc * q.ldy, n, Nr);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) vx[kt][u] = ld4_raw(Xn + mc * q.ldx, k + 16 * kt, Kr);
+      if (fold_ln) {
+        const long rn = (long)net * p.M + mc;
+        vxh[u] = ld4(q.f_xh + rn * HID + n);
+        vp1[u] = ld4(q.f_ps + rn * PS_W + 4 * c4);
+        vp2[u] = ld4(q.f_ps + rn * PS_W + 16 + 4 * c4);
+        vrs[u] = q.f_rstd[rn];
+      }
     }
   };
   fetch(0);
+  if (fold_ln) gq = ld4(q.f_g + net * HID + n0 + 4 * (t & 3));
   const float step = p.apply ? p.adam[0] : 0.f, sq2 = p.apply ? p.adam[1] : 1.f;
   if (wave < KT) {
 #pragma unroll
@@ -1441,6 +1463,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   AdamState fstate = sv;
   long foff = -1;
   if (want_bias && wave == 3 && lane < 16 && fn < q.N) { foff = nbase + q.b_off + fn; fstate = adam_fetch(p, foff); }
+  const bool fold_vec = fold_ln && tk == 0;                // dgamma1 / dbeta1 of the 16 columns: wave 3, lanes 16 .. 31 / 32 .. 47
+  if (fold_vec && wave == 3 && lane >= 16 && lane < 48) { foff = nbase + (lane < 32 ? q.f_g_off : q.f_be_off) + fn; fstate = adam_fetch(p, foff); }
   for (int mb = 0; mb < p.M; mb += 256) {
     if (mb) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -1449,6 +1473,21 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u, c4 = i & 3;
       const bool row_ok = mb + (i >> 2) < p.M;
+      if (fold) {                                          // N = HID: no column mask
+        float4 dz = row_ok ? vy[u] : f4(0.f);
+        if (fold_ln) {
+          const float a1 = sum4(vp1[u]), a2 = sum4(vp2[u]);                       // 4 of the 16 tile partials each; the quad holds the row
+          const float s1 = (dpp_mov<0x00>(a1) + dpp_mov<0x55>(a1)) + (dpp_mov<0xAA>(a1) + dpp_mov<0xFF>(a1));   // quad_perm broadcasts
+          const float s2 = (dpp_mov<0x00>(a2) + dpp_mov<0x55>(a2)) + (dpp_mov<0xAA>(a2) + dpp_mov<0xFF>(a2));
+          const float m1 = s1 * (1.0f / HID), m2 = s2 * (1.0f / HID);
+          const float4 dy = dz;
+          cg = cg + dy * vxh[u]; cb = cb + dy;
+          dz = (dy * gq - f4(m1) - vxh[u] * m2) * vrs[u];                         // ln_bwd's expression
+          if (!row_ok) dz = f4(0.f);
+        }
+        st4(Ys + (i >> 2) * YS + 4 * c4, dz);
+        if (tk == 0 && row_ok && q.f_dz) st4(q.f_dz + ((long)net * p.M + mb + (i >> 2)) * HID + n0 + 4 * c4, dz);
+      } else
       st4(Ys + (i >> 2) * YS + 4 * c4, mask4_cols(vy[u], n0 + 4 * c4, q.N, row_ok));
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) st4(Xs + kt * 256 * YS + (i >> 2) * YS + 4 * c4, mask4_cols(vx[kt][u], k0 + 4 * c4 + 16 * kt, q.K, row_ok));
@@ -1479,6 +1518,15 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) st4(red + ((kt * 4 + wave) * 64 + lane) * 4, make_float4(acc[kt][0], acc[kt][1], acc[kt][2], acc[kt][3]));
   if (want_bias) cred[fpart * 17 + fcol] = asum;
+  if (fold_vec) {                                          // lanes with equal (lane & 3) hold the same 4 columns: sum the 4 of a DPP row,
+    float v[8] = {cg.x, cg.y, cg.z, cg.w, cb.x, cb.y, cb.z, cb.w};     // then one partial per (wave, row) into LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] += dpp_mov<0x124>(v[j]); v[j] += dpp_mov<0x128>(v[j]); }   // row_ror:4, row_ror:8
+    if ((lane & 15) < 4) {
+      float* d = fsum + ((wave * 4 + (lane >> 4)) * 4 + (lane & 3)) * 8;
+      st4(d, make_float4(v[0], v[1], v[2], v[3])); st4(d + 4, make_float4(v[4], v[5], v[6], v[7]));
+    }
+  }
   __syncthreads();
   STAMP(3);
   if (wave < KT && ecol < q.ldw) {
@@ -1493,8 +1541,14 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   }
   if (foff >= 0) {
     float v = 0.f;
+    if (lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v += cred[i * 17 + fcol];
+      for (int i = 0; i < 16; ++i) v += cred[i * 17 + fcol];
+    } else {
+      const float* f = fsum + (fcol >> 2) * 8 + (lane < 32 ? 0 : 4) + (fcol & 3);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v += f[i * 32];
+    }
     adam_commit(p, foff, v, fstate, step, sq2);
   }
   STAMP(4);
@@ -2257,7 +2311,25 @@ __global__ __launch_bounds__(16 * RPB) void k_critic_tail(CriticTail p) {
 // stored once per row block is spread over the row block's column-tile blocks: each stores ITS 16 NT columns of dz2 and of the
 // three column partials; the scalars (q, target q, y, loss partials) come from the column-tile-0 block.  One graph node and one
 // cold round trip fewer per critic update; the price is 57 KB of tail operands per block instead of 16 KB of dz2 rows.
-struct CtailNn { CriticTail c; const float* Wt; int ldw; float* dX; int xr; };
+// fold != 0: dX gets dy1 = relu'(.) dh1 instead of dh1, and ps[net][row][tile] / [16 + tile] the row's two LayerNorm-backward
+// sums over this 16-column tile (TnProb::fold): h1 / xh1 = layer 1's activations and xhat, g1 = its gamma.
+struct NnFold { int fold, ln; const float* h1; const float* xh1; int g1_off; float* ps; float* gsnap; };   // gsnap[net][HID] = gamma1 (TnProb::f_g)
+struct CtailNn { CriticTail c; const float* Wt; int ldw; float* dX; int xr; NnFold f; };
+// (wave-uniform caller; o[i] = dh1 of row 4 (lane >> 4) + i of the 16-row block, column `col`)
+__device__ __forceinline__ void nn_fold_store(const NnFold& f, const float* o, const float* hv, const float* xv, float gcol,
+                                              float* x, float* ps, int row0, int B, int col, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int orow = row0 + 4 * (lane >> 4) + i;
+    const float dy = f.fold ? (hv[i] > 0.f ? o[i] : 0.f) : o[i];
+    if (orow < B) x[(long)orow * HID + col] = dy;
+    if (f.fold && f.ln) {
+      const float dxh = dy * gcol;
+      const float s1 = row16_sum(dxh), s2 = row16_sum(dxh * xv[i]);
+      if ((lane & 15) == 0 && orow < B) { ps[(long)orow * PS_W + (col >> 4)] = s1; ps[(long)orow * PS_W + 16 + (col >> 4)] = s2; }
+    }
+  }
+}
 template <int NT>
 __global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
   const CriticTail& p = a.c;
@@ -2297,6 +2369,16 @@ __global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
       const float* w = Wc + (long)(16 * c) * a.ldw;
       bv[nt][c] = make_float4(w[0], w[a.ldw], w[2 * (long)a.ldw], w[3 * (long)a.ldw]);
     }
+  }
+  float fh[4] = {1.f, 1.f, 1.f, 1.f}, fx[4] = {0.f, 0.f, 0.f, 0.f}, fg = 1.f;      // the epilogue's layer-1 operands (waves < NT)
+  if (a.f.fold && wave < NT) {
+    const int col = c_lo + 16 * wave + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long o = ((long)net * p.B + min(tm * 16 + 4 * (lane >> 4) + i, p.B - 1)) * HID + col;
+      fh[i] = a.f.h1[o]; if (a.f.ln) fx[i] = a.f.xh1[o];
+    }
+    if (a.f.ln) { fg = Pn[a.f.g1_off + col]; if (tm == 0 && lane < 16) a.f.gsnap[net * HID + col] = fg; }
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- the tail (k_critic_tail's arithmetic, agents/agent.py:208-233)
@@ -2381,12 +2463,7 @@ __global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
     const float4 x0 = ld4(rr), x1 = ld4(rr + 256), x2 = ld4(rr + 512), x3 = ld4(rr + 768);
     const float o[4] = {(x0.x + x1.x) + (x2.x + x3.x), (x0.y + x1.y) + (x2.y + x3.y), (x0.z + x1.z) + (x2.z + x3.z), (x0.w + x1.w) + (x2.w + x3.w)};
     const int col = c_lo + 16 * wave + (lane & 15);
-    float* x = a.dX + (long)net * p.B * HID;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int orow = tm * 16 + 4 * (lane >> 4) + i;
-      if (orow < p.B) x[(long)orow * HID + col] = o[i];
-    }
+    nn_fold_store(a.f, o, fh, fx, fg, a.dX + (long)net * p.B * HID, a.f.ps + (long)net * p.B * PS_W, tm * 16, p.B, col, lane);
   }
 }
 
@@ -2825,7 +2902,7 @@ __global__ __launch_bounds__(16 * RPB) void k_actor_head_bwd_s(ActorHeadBwd p) {
 // actor's dh1 = dz2 W2.  Every block redoes the head backward of its 16 rows (k_actor_head_bwd_s's arithmetic: lane n of a row
 // computes du[n], DPP row broadcast, nh FMAs per column, LayerNorm backward), keeps the dz2 rows in LDS as the A operand, and
 // stores ITS 16 columns of dz2 and of the two column partials; du comes from the column-tile-0 block.
-struct HeadBwdNn { ActorHeadBwd c; const float* Wt; int ldw; float* dX; int xr; };
+struct HeadBwdNn { ActorHeadBwd c; const float* Wt; int ldw; float* dX; int xr; NnFold f; };
 __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
   const ActorHeadBwd& p = a.c;
   constexpr int CB = 16;
@@ -2866,6 +2943,16 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
       const float* wp = Wc + (long)(16 * c) * a.ldw;
       bv[c] = make_float4(wp[0], wp[a.ldw], wp[2 * (long)a.ldw], wp[3 * (long)a.ldw]);
     }
+  }
+  float fh[4] = {1.f, 1.f, 1.f, 1.f}, fx[4] = {0.f, 0.f, 0.f, 0.f}, fg = 1.f;      // the epilogue's layer-1 operands (wave 0)
+  if (a.f.fold && wave == 0) {
+    const int col = c_lo + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long o = (long)min(tm * 16 + 4 * (lane >> 4) + i, p.B - 1) * HID + col;
+      fh[i] = a.f.h1[o]; if (a.f.ln) fx[i] = a.f.xh1[o];
+    }
+    if (a.f.ln) { fg = p.P[a.f.g1_off + col]; if (tm == 0 && lane < 16) a.f.gsnap[col] = fg; }
   }
   __builtin_amdgcn_sched_barrier(0);
   PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
@@ -2932,13 +3019,9 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) { const float4 av = ld4(Dz + r * AS + nb + 16 * c); MFMA4(acc, av, bv[c]); }
   acc = splitk_reduce(red, acc, wave, lane);
-  const int col = c_lo + (lane & 15);
   if (wave == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int orow = tm * 16 + 4 * (lane >> 4) + i;
-      if (orow < p.B) a.dX[(long)orow * HID + col] = acc[i];
-    }
+    const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    nn_fold_store(a.f, o, fh, fx, fg, a.dX, a.f.ps, tm * 16, p.B, c_lo + (lane & 15), lane);
   }
 }
 
