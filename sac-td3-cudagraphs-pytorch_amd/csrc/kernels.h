@@ -2317,7 +2317,8 @@ struct NnFold { int fold, ln; const float* h1; const float* xh1; int g1_off; flo
 struct CtailNn { CriticTail c; const float* Wt; int ldw; float* dX; int xr; NnFold f; };
 // (wave-uniform caller; o[i] = dh1 of row 4 (lane >> 4) + i of the 16-row block, column `col`)
 __device__ __forceinline__ void nn_fold_store(const NnFold& f, const float* o, const float* hv, const float* xv, float gcol,
-                                              float* x, float* ps, int row0, int B, int col, int lane) {
+                                              float* x, float* ps, float* gsnap, int row0, int B, int col, int lane) {
+  if (f.fold && f.ln && row0 == 0 && lane < 16) gsnap[col] = gcol;     // (here, not at the load: a store there waits for every load)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int orow = row0 + 4 * (lane >> 4) + i;
@@ -2378,7 +2379,7 @@ __global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
       const long o = ((long)net * p.B + min(tm * 16 + 4 * (lane >> 4) + i, p.B - 1)) * HID + col;
       fh[i] = a.f.h1[o]; if (a.f.ln) fx[i] = a.f.xh1[o];
     }
-    if (a.f.ln) { fg = Pn[a.f.g1_off + col]; if (tm == 0 && lane < 16) a.f.gsnap[net * HID + col] = fg; }
+    if (a.f.ln) fg = Pn[a.f.g1_off + col];
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- the tail (k_critic_tail's arithmetic, agents/agent.py:208-233)
@@ -2463,7 +2464,7 @@ __global__ __launch_bounds__(256) void k_ctail_nn(CtailNn a) {
     const float4 x0 = ld4(rr), x1 = ld4(rr + 256), x2 = ld4(rr + 512), x3 = ld4(rr + 768);
     const float o[4] = {(x0.x + x1.x) + (x2.x + x3.x), (x0.y + x1.y) + (x2.y + x3.y), (x0.z + x1.z) + (x2.z + x3.z), (x0.w + x1.w) + (x2.w + x3.w)};
     const int col = c_lo + 16 * wave + (lane & 15);
-    nn_fold_store(a.f, o, fh, fx, fg, a.dX + (long)net * p.B * HID, a.f.ps + (long)net * p.B * PS_W, tm * 16, p.B, col, lane);
+    nn_fold_store(a.f, o, fh, fx, fg, a.dX + (long)net * p.B * HID, a.f.ps + (long)net * p.B * PS_W, a.f.gsnap + net * HID, tm * 16, p.B, col, lane);
   }
 }
 
@@ -2952,7 +2953,7 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
       const long o = (long)min(tm * 16 + 4 * (lane >> 4) + i, p.B - 1) * HID + col;
       fh[i] = a.f.h1[o]; if (a.f.ln) fx[i] = a.f.xh1[o];
     }
-    if (a.f.ln) { fg = p.P[a.f.g1_off + col]; if (tm == 0 && lane < 16) a.f.gsnap[col] = fg; }
+    if (a.f.ln) fg = p.P[a.f.g1_off + col];
   }
   __builtin_amdgcn_sched_barrier(0);
   PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
@@ -3021,7 +3022,7 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
   acc = splitk_reduce(red, acc, wave, lane);
   if (wave == 0) {
     const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-    nn_fold_store(a.f, o, fh, fx, fg, a.dX, a.f.ps, tm * 16, p.B, c_lo + (lane & 15), lane);
+    nn_fold_store(a.f, o, fh, fx, fg, a.dX, a.f.ps, a.f.gsnap, tm * 16, p.B, c_lo + (lane & 15), lane);
   }
 }
 
