@@ -419,8 +419,10 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
     fl += 2.0 * nets * (double)g.M * g.pr[i].N * g.pr[i].K;
     by += 4.0 * nets * (double)g.M * (g.pr[i].N + g.pr[i].K) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
   }
+  bool fold = false;
+  for (int i = 0; i < g.nprob; ++i) fold = fold || g.pr[i].fold;
   char inst[96];
-  snprintf(inst, sizeof(inst), "k_tn<%d>.%s", kt, name);
+  snprintf(inst, sizeof(inst), fold ? "k_tn<%d,true>.%s" : "k_tn<%d>.%s", kt, name);
   g.tiles = tiles;
   if (g.pk_blocks) by += 12.0 * (g.pk.n0 + g.pk.n1);
   {   // what is not a GEMM tile goes to riding blocks (see TnArgs::fin)
@@ -442,7 +444,10 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   }
   const dim3 grid((unsigned)(tiles + g.pk_blocks + g.fin_blocks), 1, (unsigned)nets);
   if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
-  if (kt == 2) hipLaunchKernelGGL(k_tn<2>, grid, dim3(256), 0, s, g);
+  if (fold) {
+    if (kt == 2) hipLaunchKernelGGL((k_tn<2, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_tn<1, true>), grid, dim3(256), 0, s, g);
+  } else if (kt == 2) hipLaunchKernelGGL(k_tn<2>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(k_tn<1>, grid, dim3(256), 0, s, g);
   HIPCHK(hipGetLastError());
   return 0;

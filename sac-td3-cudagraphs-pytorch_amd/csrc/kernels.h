@@ -1388,13 +1388,15 @@ __device__ __forceinline__ void adam_commit(const TnArgs& p, long off, float g, 
 
 // KT = 16-column k tiles per block (1 or 2): with 2 the dY slice is fetched and transposed once for two weight tiles, wave 0
 // and wave 1 commit one each -- used when a launch would otherwise put more than two blocks on every CU.
-template <int KT>
+// FOLD: the instance whose layer-1 problem applies the LayerNorm backward itself (TnProb::fold); launches without such a problem
+// take the plain instance (the fold's operands cost registers: the actor's B = 1024 launch was 5 us slower through one kernel).
+template <int KT, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float red[KT * 4 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float Ys[256 * YS];
   __shared__ __attribute__((aligned(16))) float Xs[KT * 256 * YS];
   __shared__ float cred[16 * 17];                        // bias gradient: [16 partial groups][16 columns]
-  __shared__ __attribute__((aligned(16))) float fsum[16 * 4 * 8];   // folded LayerNorm backward: [wave x DPP row][column quad][dgamma 4 | dbeta 4]
+  __shared__ __attribute__((aligned(16))) float fsum[FOLD ? 16 * 4 * 8 : 4];   // folded LayerNorm backward: [wave x DPP row][column quad][dgamma 4 | dbeta 4]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
   if ((int)blockIdx.x >= p.tiles) {                         // (block-uniform) riding blocks
@@ -1426,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;                                       // thread (col = t & 15, part = t >> 4): partial column sums of dY
   float4 vy[4], vx[KT][4];
-  const bool fold = q.fold != 0, fold_ln = fold && q.f_ln;           // (block-uniform)
+  const bool fold = FOLD && q.fold != 0, fold_ln = fold && q.f_ln;   // (block-uniform)
   float4 vxh[4], vp1[4], vp2[4], gq = f4(1.f), cg = f4(0.f), cb = f4(0.f);
   float vrs[4];
   auto fetch = [&](int mb) {                      // raw loads; masked when the slab is parked in LDS, a stage later (see ld4_raw)
