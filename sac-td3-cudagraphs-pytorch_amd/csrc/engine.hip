@@ -2102,3 +2102,14 @@ int sactd3_time_gather_sweep(sactd3_engine* e, int batch, int iters, float* usec
 
 }  // extern "C"
 #pragma GCC visibility pop
+
+#ifdef SACTD3_STAMPS
+// diagnostic builds only (make stamps; tools/blocks_probe.py): the per-block begin / end stamps of the last stamped launch
+extern "C" __attribute__((visibility("default"))) int sactd3_debug_blocks(sactd3_engine* e, long long* out, int n) {
+  if (!e || !out || n < 1 || n > 4096) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 2 * n));
+  return 0;
+}
+#endif

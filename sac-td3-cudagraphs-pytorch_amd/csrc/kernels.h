@@ -52,7 +52,11 @@ __device__ long long g_phase[8];
 #define PHASE_DRAIN(i) do { __builtin_amdgcn_s_waitcnt(0); const long long n_ = clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
 #define PHASE_OUT do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) for (int i_ = 0; i_ < 6; ++i_) g_phase[i_] = ph_acc[i_]; } while (0)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0) { __builtin_amdgcn_s_waitcnt(0); g_stamps[i] = clock64(); } } while (0)
+// per-block timeline of a launch (tools/blocks_probe.py): begin / end of every block on the 100 MHz device-wide clock
+__device__ long long g_blk[4096 * 2];
+#define BLK_MARK(e) do { if (e) __syncthreads(); if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { if (e) __builtin_amdgcn_s_waitcnt(0); g_blk[2 * b_ + (e)] = wall_clock64(); } } } while (0)
 #else
+#define BLK_MARK(e)
 #define STAMP(i)
 #define PHASE_DECL
 #define PHASE_START
@@ -1399,10 +1403,12 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   __shared__ __attribute__((aligned(16))) float fsum[FOLD ? 16 * 4 * 8 : 4];   // folded LayerNorm backward: [wave x DPP row][column quad][dgamma 4 | dbeta 4]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
   const int r = lane & 15, kq = lane >> 4;
+  BLK_MARK(0);
   if ((int)blockIdx.x >= p.tiles) {                         // (block-uniform) riding blocks
     const int x = (int)blockIdx.x - p.tiles;
     if (x < p.pk_blocks) { if (net == 0) polyak_body(p.pk, x, p.pk_blocks); }
     else adam_red_tail_body(p.fin, x - p.pk_blocks, net);
+    BLK_MARK(1);
     return;
   }
   int pi = 0;
@@ -1554,6 +1560,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     adam_commit(p, foff, v, fstate, step, sq2);
   }
   STAMP(4);
+  BLK_MARK(1);
 }
 
 // ---- large-batch form of the weight gradients (M >= 1024).  k_tn's 16 x 16 tiles make every block re-read a [M][16]
