@@ -2112,4 +2112,11 @@ extern "C" __attribute__((visibility("default"))) int sactd3_debug_blocks(sactd3
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 2 * n));
   return 0;
 }
+extern "C" __attribute__((visibility("default"))) int sactd3_debug_phases(sactd3_engine* e, long long* out, int n) {
+  if (!e || !out || n < 1 || n > 4096) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ph), sizeof(long long) * 8 * n));
+  return 0;
+}
 #endif

@@ -55,7 +55,10 @@ __device__ long long g_phase[8];
 // per-block timeline of a launch (tools/blocks_probe.py): begin / end of every block on the 100 MHz device-wide clock
 __device__ long long g_blk[4096 * 2];
 #define BLK_MARK(e) do { if (e) __syncthreads(); if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { if (e) __builtin_amdgcn_s_waitcnt(0); g_blk[2 * b_ + (e)] = wall_clock64(); } } } while (0)
+__device__ long long g_ph[4096 * 8];
+#define BLK_PH(i) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { __builtin_amdgcn_s_waitcnt(0); g_ph[8 * b_ + (i)] = wall_clock64(); } } } while (0)
 #else
+#define BLK_PH(i)
 #define BLK_MARK(e)
 #define STAMP(i)
 #define PHASE_DECL
@@ -96,12 +99,21 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned ma
 // dealt round-robin over the 8 XCDs by linear id, so the blocks b = x (mod 8) share an L2: they get a compact (R / xr) x (C / xc)
 // sub-grid of the R x C tile grid (xr xc = 8).  A GEMM whose row operand is A bytes and column operand W bytes then fetches
 // xc A + xr W in total instead of 8 A + W.  Needs R % xr == 0 and C % xc == 0 (the host checks; xr = 0: row-major numbering).
+// n / d for 0 <= n < 2^22, d >= 1: a float reciprocal and one correction step -- the generic 32-bit division is ~40 dependent
+// instructions, and the tile decode sits in front of every GEMM-shaped kernel's first load
+__device__ __forceinline__ int small_div(int n, int d) {
+  int q = (int)((float)n * __frcp_rn((float)d));
+  const int r = n - q * d;
+  if (r < 0) --q; else if (r >= d) ++q;
+  return q;
+}
 __device__ __forceinline__ void xcd_tile(int b, int R, int C, int xr, int& tr, int& tc) {
-  if (xr <= 0) { tr = b / C; tc = b - tr * C; return; }
-  const int xc = 8 / xr, x = b & 7, j = b >> 3;
-  const int cl = C / xc, rl = R / xr;
-  const int gr = x / xc, gc = x - gr * xc;
-  const int jr = j / cl;
+  if (xr <= 0) { tr = small_div(b, C); tc = b - tr * C; return; }
+  const int lr = __builtin_ctz((unsigned)xr), lc = 3 - lr;      // xr in {1, 2, 4, 8}, xc = 8 / xr: shifts, the host guarantees divisibility
+  const int x = b & 7, j = b >> 3;
+  const int cl = C >> lc, rl = R >> lr;
+  const int gr = x >> lc, gc = x - (gr << lc);
+  const int jr = small_div(j, cl);
   tr = gr * rl + jr; tc = gc * cl + (j - jr * cl);
 }
 
@@ -1414,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   int pi = 0;
   if (p.nprob > 1 && (int)blockIdx.x >= p.pr[1].tile0) pi = 1;
   if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
-  const TnProb& q = p.pr[pi];    // stays in the kernarg segment (a private copy indexed at run time would be scratch memory)
+  const TnProb q = p.pr[pi];     // ONE batch of scalar loads for the whole problem (field-by-field they came in 3-4 dependent rounds)
   const int local = blockIdx.x - q.tile0;
   const int tiles_k = (((q.ldw + 15) >> 4) + KT - 1) / KT;
   int tn, tk;
@@ -1424,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   // the epilogue's elements: wave kt < KT, lane (j = lane & 15, rq = lane >> 4) owns rows n0 + 4 rq + i, column k0 + 16 kt + j
   const int ecol = k0 + 16 * min(wave, KT - 1) + (lane & 15);
   AdamState st[4], sv = {0.f, 0.f, 0.f, 0.f};
-  STAMP(0);
+  STAMP(0); BLK_PH(0);
   // operand tiles are column slices ([M rows][16 floats]): fetched as float4 (64-byte pieces), transposed through LDS
   const float* dYn = q.dY + net * q.dy_ns;
   const float* Xn = q.X + net * q.x_ns;
@@ -1476,7 +1488,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   for (int mb = 0; mb < p.M; mb += 256) {
     if (mb) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(1);
+    STAMP(1); BLK_PH(1);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = t + 256 * u, c4 = i & 3;
@@ -1521,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
       for (int i = 0; i < 16; ++i) asum += Ys[(part * 16 + i) * YS + col];
     }
   }
-  STAMP(2);
+  STAMP(2); BLK_PH(2);
   // sum the 4 waves' accumulators of every tile (split-M); wave kt gets the total of tile kt
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) st4(red + ((kt * 4 + wave) * 64 + lane) * 4, make_float4(acc[kt][0], acc[kt][1], acc[kt][2], acc[kt][3]));
@@ -1536,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
   }
   __syncthreads();
-  STAMP(3);
+  STAMP(3); BLK_PH(3);
   if (wave < KT && ecol < q.ldw) {
     const float* rr = red + (wave * 4 * 64 + lane) * 4;
     const float4 a = ld4(rr), b = ld4(rr + 256), c = ld4(rr + 512), d = ld4(rr + 768);
@@ -1559,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
     }
     adam_commit(p, foff, v, fstate, step, sq2);
   }
-  STAMP(4);
+  STAMP(4); BLK_PH(4);
   BLK_MARK(1);
 }
 

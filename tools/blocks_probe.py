@@ -24,5 +24,12 @@ for rep in range(3):
     live = np.where(ok)[0]
     print(f"rep {rep}: {len(live)} blocks; launch span {end[live].max()} ns; begin: p50 {np.median(beg[live]):.0f} max {beg[live].max()} ns; duration p50 {np.median((end - beg)[live]):.0f} max {(end - beg)[live].max()} ns")
     if rep == 2:
+        ph = (C.c_longlong * (8 * n))()
+        lib.sactd3_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
+        assert lib.sactd3_debug_phases(eng._h, ph, n) == 0
+        P = (np.array(ph[:], np.int64).reshape(n, 8)[:, :5] - t0) * 10
+        for b in live:
+            if P[b, 0] > -1000:
+                print(f"  phases {b:4d} begin {beg[b]:5d} | loads issued {P[b,0]:5d} landed {P[b,1]:5d} mfma done {P[b,2]:5d} reduced {P[b,3]:5d} committed {P[b,4]:5d} | end {end[b]:5d}")
         for b in live:
             print(f"  block {b:4d} begin {beg[b]:6d} end {end[b]:6d} dur {end[b] - beg[b]:6d}")
