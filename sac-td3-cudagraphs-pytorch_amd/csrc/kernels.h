@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(256) void k_tn64(Tn64Args p) {
   int pi = 0;
   if (p.nprob > 1 && L >= p.pr[1].tile0) pi = 1;
   if (p.nprob > 2 && L >= p.pr[2].tile0) pi = 2;
-  const Tn64Prob& q = p.pr[pi];
+  const Tn64Prob q = p.pr[pi];   // by value: one batch of scalar loads (see k_tn)
   L -= q.tile0;
   const int tn = L / q.tiles_k, tk = L - tn * q.tiles_k;
   const int n0 = tn * TN, k0 = tk * TK;
