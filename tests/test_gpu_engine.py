@@ -231,7 +231,10 @@ def test_synthetic_fill_statistics():
 # k_actor_head_bwd -- every intermediate and every per-key gradient against oracle/manual_grads.py, like the small-batch forms
 CASES = [("sac", "hopper", 256, True), ("sac", "hopper", 40, False), ("td3", "halfcheetah", 256, True),
          ("sac", "humanoid", 96, True), ("sac", "humanoid", 1024, True), ("td3", "humanoid", 1024, True),
-         ("sac", "hopper", 1024, True), ("sac", "humanoid", 1024, False)]
+         ("sac", "hopper", 1024, True), ("sac", "humanoid", 1024, False),
+         # more than one 256-row slab below B = 1024: the fused row + GEMM launches with a ragged last row block, and k_tn's folded
+         # LayerNorm backward across two slabs (the second one partly masked)
+         ("sac", "hopper", 300, True), ("td3", "halfcheetah", 512, True)]
 
 
 @pytest.mark.parametrize("algo,env,B,ln", CASES)
