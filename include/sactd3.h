@@ -171,6 +171,11 @@ int sactd3_step(sactd3_engine* e, int do_actor);
  * critic-only: one period of the schedule of :345-349 -- as ONE graph launch.  Equal to that many sactd3_step calls, bit for
  * bit.  Needs TD3 or crit_targ_update_freq == 1 (else SACTD3_ESTATE: issue the iterations with sactd3_step). */
 int sactd3_step_period(sactd3_engine* e);
+/* The first m iterations of a period (1 <= m <= actor_update_delay: the one with the actor updates + m - 1 critic-only ones) as ONE
+ * graph launch -- what a run of iterations leaves behind its last whole period (orchestrator.py:337-352 with a number of
+ * iterations that is not a multiple of the period).  Equal to sactd3_step(e, 1) followed by m - 1 sactd3_step(e, 0), bit for bit.
+ * Same preconditions as sactd3_step_period. */
+int sactd3_step_prefix(sactd3_engine* e, int m);
 /* Capture and instantiate the hipGraphs of sactd3_step / sactd3_step_period now rather than at their first use (the reference's
  * CudaGraphModule captures after a warm-up inside the loop, orchestrator.py:313-315); nothing is launched, no state changes. */
 int sactd3_instantiate_graphs(sactd3_engine* e);
@@ -193,7 +198,8 @@ int sactd3_sync(sactd3_engine* e);                                          /* [
  * With dst == NULL only the size is returned. Names: see sactd3_debug_names(). [sync] */
 int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_t max_floats);
 const char* sactd3_debug_names(void);
-/* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1), 4 step_period */
+/* number of kernel nodes in the instantiated graph of: 0 update_qnets, 1 update_actor, 2 step(do_actor=0), 3 step(do_actor=1), 4 step_period,
+ * 5 the opening graph of a period that cannot use a precomputed opening pair, 6 / 7 step_prefix(1) / step_prefix(2) */
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph);
 /* average device time in microseconds of `iters` back-to-back launches of one kernel of the path,
  * measured with hipEvents on the engine's stream: "gather" (a fresh index draw per launch), "polyak", "trunk_critics" (the 4-net

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sactd3_read_batch", "sactd3_rb_fill_synthetic", "sactd3_set_noise", "sactd3_clear_noise", "sactd3_read_noise",
     "sactd3_update_qnets", "sactd3_update_actor", "sactd3_update_targ_nets", "sactd3_step", "sactd3_predict",
     "sactd3_read_metrics", "sactd3_sync", "sactd3_debug_read", "sactd3_debug_names", "sactd3_graph_kernel_count",
-    "sactd3_time_kernel", "sactd3_time_gather_sweep", "sactd3_time_nodes", "sactd3_rb_layout", "sactd3_rb_extend_device", "sactd3_step_period", "sactd3_instantiate_graphs", "sactd3_device_handles",
+    "sactd3_time_kernel", "sactd3_time_gather_sweep", "sactd3_time_nodes", "sactd3_rb_layout", "sactd3_rb_extend_device", "sactd3_step_period", "sactd3_step_prefix", "sactd3_instantiate_graphs", "sactd3_device_handles",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
         "sactd3_update_targ_nets": (C.c_int, [vp, C.c_int64]),
         "sactd3_step": (C.c_int, [vp, C.c_int]),
         "sactd3_step_period": (C.c_int, [vp]),
+        "sactd3_step_prefix": (C.c_int, [vp, C.c_int]),
         "sactd3_instantiate_graphs": (C.c_int, [vp]),
         "sactd3_predict": (C.c_int, [vp, fp, C.c_int, C.c_int, fp]),
         "sactd3_read_metrics": (C.c_int, [vp, fp]),

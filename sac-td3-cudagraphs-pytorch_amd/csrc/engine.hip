@@ -74,7 +74,8 @@ static void unpack_net(const NetLayout& L, int ln, const float* src, float* dst)
 }
 
 static const int BIG_BATCH = 1024;   // from here on the hidden layers run as 64 x 64-tiled GEMMs + a LayerNorm row kernel
-enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_PERIOD = 6, G_PERIOD_B = 7, G_OPENING = 8, G_COUNT = 9 };
+enum { G_Q = 0, G_A = 1, G_STEP00 = 2, G_STEP01 = 3, G_STEP10 = 4, G_STEP11 = 5, G_PERIOD = 6, G_PERIOD_B = 7, G_OPENING = 8,
+       G_PREFIX = 9 /* + 2 (m - 1) + variant, m = 1, 2: the first m iterations of a period (sactd3_step_prefix) */, G_COUNT = 13 };
 static const int NSTAGE = 32;
 
 struct NodeInfo { std::string name; double flops; double bytes; long threads; };
@@ -1763,6 +1764,16 @@ static int enqueue_period(sactd3_engine* e, hipStream_t s, int variant = 0) {
   if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_period: a deferred temperature step was left over");
   return 0;
 }
+// The first m <= delay iterations of a period (pipelined form): the period graph cut short -- the iteration with the actor updates on
+// the precomputed opening pair of slot P, the sampling and next-action passes of the m - 1 critic-only iterations behind it run ahead,
+// nothing is left behind for a next period.
+static int enqueue_prefix(sactd3_engine* e, hipStream_t s, int variant, int m) {
+  const int P = variant ? 3 : 0;
+  RCCHK(enqueue_step(e, s, true, true, m > 1, P, true, m - 1, -1, true));
+  for (int i = 1; i < m; ++i) RCCHK(enqueue_step(e, s, false, true, i + 1 < m, i, true));
+  if (e->alpha_pending) return e->fail(SACTD3_ESTATE, "step_prefix: a deferred temperature step was left over");
+  return 0;
+}
 // the opening pair of a period's first iteration into batch slot `slot`, without its counter ticks (enqueue_update_qnets, open_mode 1)
 static int enqueue_opening(sactd3_engine* e, hipStream_t s, int slot) {
   bool policy_done = false;
@@ -1799,6 +1810,30 @@ int sactd3_step_period(sactd3_engine* e) {
   return 0;
 }
 
+// The first m iterations of a period (1 <= m <= actor_update_delay) as ONE graph launch: what is left of a run of iterations behind
+// its last whole period (orchestrator.py:337-352 for a number of iterations that is not a multiple of the period).  Equal to
+// sactd3_step(1) followed by m - 1 sactd3_step(0), bit for bit; in the pipelined form it uses the opening pair the previous period
+// left behind (or runs the opening graph) exactly as sactd3_step_period does.  Same preconditions as sactd3_step_period.
+int sactd3_step_prefix(sactd3_engine* e, int m) {
+  if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  if (m < 1 || m > e->cfg.actor_update_delay) return e->fail(SACTD3_EINVAL, "step_prefix: 1 <= m <= actor_update_delay");
+  if (e->rb_len <= 0) return e->fail(SACTD3_ESTATE, "step_prefix: buffer is empty");
+  if (!e->cfg.prefer_td3_over_sac && e->cfg.crit_targ_update_freq != 1) return e->fail(SACTD3_ESTATE, "step_prefix: needs crit_targ_update_freq == 1");
+  if (!period_is_pipelined(e) || m > 2) {      // no cut-short form: the iterations one by one
+    for (int i = 0; i < m; ++i) RCCHK(sactd3_step(e, i == 0));
+    return 0;
+  }
+  const int v = e->chain_ready >= 0 ? e->chain_ready : 0;
+  const bool have = e->chain_ready >= 0;
+  e->chain_ready = -1;
+  if (!have) RCCHK(run_graph(e, G_OPENING, [&](hipStream_t s) { return enqueue_opening(e, s, 0); }));
+  RCCHK(run_graph(e, G_PREFIX + 2 * (m - 1) + v, [&](hipStream_t s) { return enqueue_prefix(e, s, v, m); }));
+  e->cur_slot = m - 1;
+  e->qnet_updates += m;
+  return 0;
+}
+
 // Capture + instantiate the graphs of sactd3_step (both schedules, with the target update) and sactd3_step_period now instead of
 // at their first use, without launching anything: a caller that times its first iterations (or must not stall in the loop) calls
 // this once after sactd3_create.  No-op with use_graphs == 0.
@@ -1816,6 +1851,9 @@ int sactd3_instantiate_graphs(sactd3_engine* e) {
     if (period_is_pipelined(e)) {
       RCCHK(run_graph(e, G_PERIOD_B, [&](hipStream_t s) { return enqueue_period(e, s, 1); }, false));
       RCCHK(run_graph(e, G_OPENING, [&](hipStream_t s) { return enqueue_opening(e, s, 0); }, false));
+      for (int m = 1; m <= e->cfg.actor_update_delay && m <= 2; ++m)
+        for (int v = 0; v < 2; ++v)
+          RCCHK(run_graph(e, G_PREFIX + 2 * (m - 1) + v, [&](hipStream_t s) { return enqueue_prefix(e, s, v, m); }, false));
     }
   }
   return 0;
@@ -1958,8 +1996,8 @@ int64_t sactd3_debug_read(sactd3_engine* e, const char* name, float* dst, int64_
 
 int sactd3_graph_kernel_count(sactd3_engine* e, int which_graph) {
   if (!e) return SACTD3_EINVAL;
-  static const int map[6] = {G_Q, G_A, G_STEP01, G_STEP11, G_PERIOD, G_OPENING};
-  if (which_graph < 0 || which_graph > 5) return SACTD3_EINVAL;
+  static const int map[8] = {G_Q, G_A, G_STEP01, G_STEP11, G_PERIOD, G_OPENING, G_PREFIX, G_PREFIX + 2};
+  if (which_graph < 0 || which_graph > 7) return SACTD3_EINVAL;
   int w = map[which_graph];
   if (!e->graphs[w] && (which_graph == 2 || which_graph == 3)) w -= 1;   // the no-Polyak variant, if that is the one in use
   return e->graph_nodes[w];

@@ -262,6 +262,10 @@ class Engine:
     def step(self, do_actor: bool) -> None:
         self._ck(self.lib.sactd3_step(self._h, int(bool(do_actor))))
 
+    def step_prefix(self, m: int) -> None:
+        """the first m iterations of a period (the one with the actor updates + m - 1 critic-only ones) in one graph launch"""
+        self._ck(self.lib.sactd3_step_prefix(self._h, int(m)))
+
     def step_period(self) -> None:
         """actor_update_delay + 1 iterations (actor updates in the first) as one graph launch."""
         self._ck(self.lib.sactd3_step_period(self._h))
@@ -280,6 +284,9 @@ class Engine:
             if can and i % period == 0 and i + period <= end:
                 self.step_period()
                 i += period
+            elif can and i % period == 0:          # what is left behind the last whole period: its first end - i iterations, one launch
+                self.step_prefix(end - i)
+                i = end
             else:
                 self.step(i % period == 0)
                 i += 1

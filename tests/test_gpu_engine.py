@@ -681,7 +681,8 @@ def test_period_graph_equals_single_iterations(algo, env, B):
         ref, eng, (o, a, bound) = make_pair(algo, env, B, seed=4)
         eng.rb_extend(*[t.numpy() for t in synth_transitions(3000, o, a, bound, seed=23)])
         if mode == "period":
-            assert eng.run_iterations(1, 10) == 11          # iterations 1, 2 singly, periods 3-5 and 6-8, then 9, 10
+            assert eng.run_iterations(1, 10) == 11          # iterations 1, 2 singly, periods 3-5 and 6-8, then 9, 10 as a cut-short period
+            eng.instantiate_graphs()                        # (the single iteration with actor updates was not needed so far: count its nodes)
             # SAC (pipelined, chained periods -- csrc/engine.hip BatchSlot / chain_ready): the period's last temperature step rides in the
             # next iteration's first launch (one node fewer); the critic-only iterations' sampling + next-action passes (trunk launch(es)
             # + tail: 2 nodes at narrow observations, 3 at wide ones) run ahead in the first iteration's last actor-trunk / tail launches,
@@ -695,6 +696,10 @@ def test_period_graph_equals_single_iterations(algo, env, B):
                 assert eng.graph_kernel_count(4) == c1 - 1 + 2 * (c0 - opening) - opening and eng.graph_kernel_count(5) == opening
             else:
                 assert eng.graph_kernel_count(4) == c1 + 2 * (c0 - opening) and eng.graph_kernel_count(5) == opening
+            # step_prefix(1): the iteration with the actor updates on a precomputed opening pair; step_prefix(2): + one critic-only iteration
+            # whose opening pair ran ahead (SAC: in the temperature pair, whose step is deferred; TD3: a trunk + tail pair of its own)
+            assert eng.graph_kernel_count(6) == c1 - opening
+            assert eng.graph_kernel_count(7) == c1 - opening + (c0 - opening) + (-1 if algo == "sac" else opening)
         else:
             for i in range(1, 11):
                 eng.step(i % 3 == 0)
@@ -744,14 +749,18 @@ def test_chained_periods_with_state_changes_in_between_equal_single_iterations(a
         it[0] += 1                                              # (counts as iteration 21: not a multiple of 3)
         run(2)                                                  # singles 22, 23 (whole periods only start at multiples of 3)
         run(6)                                                  # periods 24-26, 27-29
+        run(2)                                                  # 30, 31: the first two iterations of a period in one launch (step_prefix(2)) on the chained opening pair
+        run(1)                                                  # 32: a single critic-only iteration
+        run(1)                                                  # 33: step_prefix(1) behind a single iteration (opening graph first)
         res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR_TARGET),
                     eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"], eng.read_noise(_lib.SITE_CRITIC), acted,
                     eng.get_adam_state(_lib.CRITICS)[2], eng.get_adam_state(_lib.ACTOR)[2], np.array(list(eng.read_metrics().values()))))
         if mode == "period":
             assert eng.graph_kernel_count(5) > 0                # the opening graph exists: the chained form was in use
+            assert eng.graph_kernel_count(6) > 0 and eng.graph_kernel_count(7) > eng.graph_kernel_count(6)     # ... and both cut-short periods
     for x, y in zip(*res):
         assert np.array_equal(x, y)
-    assert res[0][8] == 30 and res[0][9] == 18
+    assert res[0][8] == 34 and res[0][9] == 22
 
 
 def test_graphs_can_be_instantiated_ahead_of_the_first_step():
@@ -1118,6 +1127,7 @@ def test_error_paths_return_codes_not_crashes():
     with pytest.raises(P.EngineError):
         eng.rb_fill_synthetic(129)                                           # beyond capacity
     assert lib.sactd3_graph_kernel_count(eng._h, 9) < 0 and lib.sactd3_sync(None) < 0
+    assert lib.sactd3_step_prefix(eng._h, 0) < 0 and lib.sactd3_step_prefix(eng._h, 3) < 0 and lib.sactd3_step_prefix(None, 1) < 0   # 1 <= m <= delay
     # the engine is still usable afterwards
     eng.rb_fill_synthetic(100)
     eng.step(True)
