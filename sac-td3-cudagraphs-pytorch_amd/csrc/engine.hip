@@ -2150,6 +2150,16 @@ extern "C" __attribute__((visibility("default"))) int sactd3_debug_blocks(sactd3
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 2 * n));
   return 0;
 }
+extern "C" __attribute__((visibility("default"))) int sactd3_debug_blocks_select(sactd3_engine* e, int kernel) {
+  if (!e) return SACTD3_EINVAL;
+  USE_DEVICE(e);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk_kernel), &kernel, sizeof(int)));
+  std::vector<long long> z(4096 * 8, 0);
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), z.data(), sizeof(long long) * 4096 * 2));
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ph), z.data(), sizeof(long long) * 4096 * 8));
+  return 0;
+}
 extern "C" __attribute__((visibility("default"))) int sactd3_debug_phases(sactd3_engine* e, long long* out, int n) {
   if (!e || !out || n < 1 || n > 4096) return SACTD3_EINVAL;
   USE_DEVICE(e);

@@ -54,12 +54,17 @@ __device__ long long g_phase[8];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0) { __builtin_amdgcn_s_waitcnt(0); g_stamps[i] = clock64(); } } while (0)
 // per-block timeline of a launch (tools/blocks_probe.py): begin / end of every block on the 100 MHz device-wide clock
 __device__ long long g_blk[4096 * 2];
-#define BLK_MARK(e) do { if (e) __syncthreads(); if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { if (e) __builtin_amdgcn_s_waitcnt(0); g_blk[2 * b_ + (e)] = wall_clock64(); } } } while (0)
 __device__ long long g_ph[4096 * 8];
-#define BLK_PH(i) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { __builtin_amdgcn_s_waitcnt(0); g_ph[8 * b_ + (i)] = wall_clock64(); } } } while (0)
+__device__ int g_blk_kernel;         // which kernel family records: 0 k_tn, 1 k_nt (sactd3_debug_blocks_select)
+#define BLK_MARK_K(k, e) do { if (g_blk_kernel == (k)) { if (e) __syncthreads(); if (threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { if (e) __builtin_amdgcn_s_waitcnt(0); g_blk[2 * b_ + (e)] = wall_clock64(); g_ph[8 * b_ + 6 + (e)] = clock64(); } } } } while (0)   /* + the shader clock: ph[7] - ph[6] cycles over end - begin */
+#define BLK_PH_K(k, i) do { if (g_blk_kernel == (k) && threadIdx.x == 0) { const int b_ = blockIdx.x + gridDim.x * blockIdx.z; if (b_ < 4096) { if ((k) == 0) __builtin_amdgcn_s_waitcnt(0); g_ph[8 * b_ + (i)] = wall_clock64(); } } } while (0)   /* k_nt: issue times only (no drain: its loads are meant to stay in flight) */
+#define BLK_MARK(e) BLK_MARK_K(0, e)
+#define BLK_PH(i) BLK_PH_K(0, i)
 #else
 #define BLK_PH(i)
 #define BLK_MARK(e)
+#define BLK_PH_K(k, i)
+#define BLK_MARK_K(k, e)
 #define STAMP(i)
 #define PHASE_DECL
 #define PHASE_START
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(256) void k_rb_fill(FillArgs p) {
 // Operand maps of v_mfma_f32_16x16x4_f32 (lane l): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
 // D: col j = l&15, row i = 4*(l>>4) + reg.  The k slot of a lane may name ANY k as long as A and B agree, so
 // lane-group kq takes 4 CONSECUTIVE k's (one 16-byte read) and feeds them to 4 successive MFMAs.
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }   // (i is a constant after unrolling)
 #define MFMA4(acc, a, b)                                                   \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).x, (b).x, acc, 0, 0, 0);  \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a).y, (b).y, acc, 0, 0, 0);  \
@@ -562,11 +568,13 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
+  BLK_MARK_K(1, 0);
   if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
     const int x = (int)blockIdx.x - p.nt_blocks;
     if (x < p.gblocks) { if (blockIdx.z == 0) riding_gather(p, x); }
     else if (blockIdx.z != 0) { }
     else riding_body(p, x - p.gblocks);
+    BLK_MARK_K(1, 1);
     return;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   float bias[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bias[nt] = p.oBias >= 0 ? Pn[p.oBias + min(n0 + 16 * nt + r, p.N - 1)] : 0.f;
-  STAMP(0);
+  STAMP(0); BLK_PH_K(1, 0);
   // ---- 1. every global load, coalesced where the data is shared by the block
   float4 w2r[4 * NT], w1r[C1 > 0 ? 4 * C1 : 1], vr = f4(0.f), xv[C1 > 0 ? C1 : 1], av[CW];
   const int w1n = FUSE1 ? (HID * p.ldw1) >> 2 : 0;           // float4s of W1 (rows are 16-byte multiples, contiguous)
@@ -639,22 +647,36 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   }
   if (t < 192) st4(vec + 4 * t, vr);
   __syncthreads();
-  STAMP(1);
+  STAMP(1); BLK_PH_K(1, 1);
   if (FUSE1) {
     // first layer as a transposed product, D[i = n1][j = m] = sum_k W1[n1][k] x[m][k]: lane (m = r, kq) receives
     // z1[m][16 (ks CW + c) + 4 kq .. +3] -- exactly its A fragment of chunk c for the second layer
+    // four tiles at a time: their W1 fragments are requested together and the MFMAs of the four (independent) accumulators alternate,
+    // so neither an LDS read nor the previous MFMA of the same tile is waited for in front of every instruction
+    constexpr int GT = CW < 4 ? CW : 4;
 #pragma unroll
-    for (int c = 0; c < CW; ++c) {
-      const int tile = ks * CW + c;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < CW; c0 += GT) {
+      float4 wf[GT][C1 > 0 ? C1 : 1], b1[GT];
+      f32x4 z[GT];
 #pragma unroll
-      for (int c1 = 0; c1 < C1; ++c1) {
-        const int k = 16 * c1 + 4 * kq;
-        const float4 wf = k < p.ldw1 ? ld4(W1s + (tile * 16 + r) * W1S + k) : f4(0.f);
-        MFMA4(z, wf, xv[c1]);
+      for (int j = 0; j < GT; ++j) {
+        const int tile = ks * CW + c0 + j;
+#pragma unroll
+        for (int c1 = 0; c1 < C1; ++c1) {
+          const int k = 16 * c1 + 4 * kq;
+          wf[j][c1] = k < p.ldw1 ? ld4(W1s + (tile * 16 + r) * W1S + k) : f4(0.f);
+        }
+        b1[j] = ld4(vec + tile * 16 + 4 * kq);
+        z[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const float4 b1 = ld4(vec + tile * 16 + 4 * kq);
-      av[c] = make_float4(z[0] + b1.x, z[1] + b1.y, z[2] + b1.z, z[3] + b1.w);
+#pragma unroll
+      for (int c1 = 0; c1 < C1; ++c1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < GT; ++j) z[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(wf[j][c1], q), f4c(xv[c1], q), z[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < GT; ++j) av[c0 + j] = make_float4(z[j][0] + b1[j].x, z[j][1] + b1[j].y, z[j][2] + b1[j].z, z[j][3] + b1[j].w);
     }
   }
 #pragma unroll
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       for (int c = 0; c < CW; ++c) { xh[c] = av[c]; av[c] = relu4(av[c]); }
     }
   }
-  STAMP(2);
+  STAMP(2); BLK_PH_K(1, 2);
   // The normalised rows are kept for the backward pass.  Every column-tile block of a row block holds the same rows, so
   // each stores only ITS share of the 16 column chunks (16 / tiles_n of them) instead of the tn == 0 blocks storing whole
   // rows: 64 KB per row block spread over all of its blocks -- those few blocks were the launch's long pole.
@@ -721,20 +743,36 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
     if (G.rstd_out && tn == 0 && ks == 0 && kq == 0) G.rstd_out[(long)ni * p.M + m0 + r] = rstd;
   }
   // ---- 4. second layer: this wave's rows x the block's 16 NT columns over its K range (W tiles from LDS)
+  // Even chunks accumulate in a0, odd ones in a1 (per column tile): 2 NT independent MFMA chains, issued alternately, with the W
+  // fragments of four chunks requested together -- no instruction waits for the LDS read or the MFMA right in front of it.  (Each
+  // accumulator still sees its chunks in the same order: the sums are bit-identical to the chunk-by-chunk loop this replaces.)
   f32x4 acc[NT];
+  {
+    constexpr int GC = CW < 4 ? CW : 4;
+    f32x4 a0[NT], a1[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    const float* wrow = W2s + (16 * nt + r) * AS + kb;
+    for (int nt = 0; nt < NT; ++nt) { a0[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int c = 0; c < CW; c += 2) {
-      const float4 w0 = ld4(wrow + 16 * c);
-      MFMA4(a0, av[c], w0);
-      if (c + 1 < CW) { const float4 w1 = ld4(wrow + 16 * c + 16); MFMA4(a1, av[c + 1], w1); }
+    for (int c0 = 0; c0 < CW; c0 += GC) {
+      float4 wv[NT][GC];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < GC; ++j) wv[nt][j] = ld4(W2s + (16 * nt + r) * AS + kb + 16 * (c0 + j));
+#pragma unroll
+      for (int j = 0; j < GC; j += 2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            a0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j], q), f4c(wv[nt][j], q), a0[nt], 0, 0, 0);
+            if (j + 1 < GC) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j + 1], q), f4c(wv[nt][j + 1], q), a1[nt], 0, 0, 0);
+          }
     }
-    acc[nt][0] = a0[0] + a1[0]; acc[nt][1] = a0[1] + a1[1]; acc[nt][2] = a0[2] + a1[2]; acc[nt][3] = a0[3] + a1[3];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { acc[nt][0] = a0[nt][0] + a1[nt][0]; acc[nt][1] = a0[nt][1] + a1[nt][1]; acc[nt][2] = a0[nt][2] + a1[nt][2]; acc[nt][3] = a0[nt][3] + a1[nt][3]; }
   }
-  STAMP(3);
+  STAMP(3); BLK_PH_K(1, 3);
   if (KS > 1) {                               // sum the KS K-slices of each 16 x 16 tile; the ks == 0 wave keeps the total
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
@@ -749,7 +787,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
         }
     }
   }
-  STAMP(4);
+  STAMP(4); BLK_PH_K(1, 4);
   if (ks == 0) {
     float* y = G.Y + ni * p.y_ns;
 #pragma unroll
@@ -763,7 +801,8 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
       }
     }
   }
-  STAMP(5);
+  STAMP(5); BLK_PH_K(1, 5);
+  BLK_MARK_K(1, 1);
 }
 
 // Generic-K form (an unfused first layer wider than 64 inputs): 16 x 16 tile per block, wave w takes k chunks w, w+4, ...
