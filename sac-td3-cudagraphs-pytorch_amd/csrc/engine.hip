@@ -110,6 +110,7 @@ struct sactd3_engine {
   float* eps[SACTD3_NUM_SITES] = {};
   float *a_z1 = nullptr, *a_xh1 = nullptr, *a_h1 = nullptr, *a_rs1 = nullptr, *a_z2 = nullptr, *a_xh2 = nullptr, *a_h2 = nullptr, *a_rs2 = nullptr, *a_tg = nullptr;
   float *a_du = nullptr, *a_dz2 = nullptr, *a_dh1 = nullptr, *a_dz1 = nullptr;
+  float *qa_ps = nullptr, *qa_S = nullptr;   // dQ/da partials of the fused actor update (QaFold): [nq][B][16][16], [nq][16][8]
   float *a_ps = nullptr, *c_ps = nullptr;     // row-sum partials of the folded layer-1 LayerNorm backward (TnProb::fold): [nets][B][PS_W]
   float* a_z2n = nullptr;        // layer-2 output of the s' pass when the pi(s) pass shares its launch
   float* ah_z1[4] = {}; float* ah_z2[4] = {};   // layer outputs of the passes that run ahead (pipelined period, see BatchSlot)
@@ -869,6 +870,9 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
   }
   e->node_role = (j & 1) ? "actor1/loss+backward" : "actor0/loss+backward";
   const bool fused_qtail_nn = B < BIG_BATCH && !(e->tune_rows4 & 2048);
+  // dQ/da finished inside the two fused launches around it (QaFold): narrow heads, ac_dim <= 7
+  const bool qa_fold = fused_qtail_nn && small_head && e->a <= 7 && !(e->tune_rows4 & 16384);    // (small_head: k_headbwd_nn is the consumer)
+  const int qa_ntile = HID / (nq == 2 ? 32 : 16), qa_pqw = e->a <= 3 ? 8 : 16;
   {
     ActorQTail t{};
     t.z2c = e->c_z2; t.P = e->Pc; t.p_ns = e->Lc.size; t.L = e->Lc; t.logp = e->logp_pi; t.log_alpha = e->la;
@@ -876,6 +880,10 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     if (fused_qtail_nn) {   // the tail AND dh1_i = dz2_i W2_i in one launch (k_qtail_nn): loss partials per 16-row block
       QtailNn f{};
       f.c = t; f.Wt = e->Pc + e->Lc.W2; f.ldw = HID; f.dX = e->c_dh1;
+      if (qa_fold) {
+        f.qa.on = 1; f.qa.ln = ln; f.qa.a = e->a; f.qa.pqw = qa_pqw; f.qa.ntile = qa_ntile; f.qa.h1 = e->c_h1; f.qa.xh1 = e->c_xh1;
+        f.qa.g1_off = e->Lc.g1; f.qa.w1_off = e->Lc.W1; f.qa.ld1 = e->Lc.ld1; f.qa.k_off = e->o; f.qa.ps = e->qa_ps; f.qa.S = e->qa_S;
+      }
       const double fl = 2.0 * nq * B * (double)HID + 2.0 * nq * (double)B * HID * HID, by = 4.0 * nq * (2.0 * BH + 4.0 * HID + 2.0 * B) + 4.0 * nq * ((double)HID * HID + (double)B * HID);
       if (nq == 2) {
         f.xr = pick_xr(e, e->nblk, HID / 32, 4.0 * 2 * B * HID, 4.0 * HID * HID);
@@ -892,7 +900,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     g.dX = e->c_dh1; g.ldx = HID; g.dx_ns = BH; g.M = B; g.Kout = HID;
     RCCHK(launch_nn(e, s, "k_nn.dh1", g, nq));
   }
-  {
+  if (!qa_fold) {
     LnBwd l{};
     l.dh = e->c_dh1; l.xh = e->c_xh1; l.h = e->c_h1; l.rstd = e->c_rs1;
     l.gamma = e->Pc + e->Lc.g1; l.p_ns = e->Lc.size; l.B = B; l.ln = ln; l.want_part = 0;
@@ -913,6 +921,10 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
     if (fused_head_nn) {   // the head backward AND dh1 = dz2 W2 in one launch (k_headbwd_nn): column partials per 16-row block
       HeadBwdNn f{};
       f.c = h; f.Wt = e->Pa + e->La.W2; f.ldw = HID; f.dX = e->a_dh1;
+      if (qa_fold) {
+        f.qa.on = 1; f.qa.ln = ln; f.qa.a = e->a; f.qa.pqw = qa_pqw; f.qa.ntile = qa_ntile; f.qa.ps = e->qa_ps; f.qa.S = e->qa_S;
+        f.qa.rstd = e->c_rs1; f.qa.dA = e->dA;
+      }
       fold_ln1 = !(e->tune_rows4 & 4096);   // as the critics' (enqueue_update_qnets)
       f.f.fold = fold_ln1; f.f.ln = ln; f.f.h1 = e->a_h1; f.f.xh1 = e->a_xh1; f.f.g1_off = e->La.g1; f.f.ps = e->a_ps; f.f.gsnap = e->a_ps + (long)B * PS_W;
       f.xr = pick_xr(e, e->nblk, HID / 16, 4.0 * 2 * B * HID, 4.0 * HID * HID);
@@ -1316,6 +1328,7 @@ static int create_impl(sactd3_engine* e, const float* min_ac, const float* max_a
     RCCHK(dalloc(e, &S.logp_n, B)); RCCHK(dalloc(e, &S.eps_c, std::max<size_t>(B, e->maxn) * e->a)); RCCHK(dalloc(e, &S.idx, B));
   }
   RCCHK(dalloc(e, &e->a_dz2, BH)); RCCHK(dalloc(e, &e->a_dh1, BH)); RCCHK(dalloc(e, &e->a_dz1, BH));
+  RCCHK(dalloc(e, &e->qa_ps, 2L * B * 256)); RCCHK(dalloc(e, &e->qa_S, 2L * 16 * 8));
   RCCHK(dalloc(e, &e->a_ps, (long)B * PS_W + HID)); RCCHK(dalloc(e, &e->c_ps, 2L * B * PS_W + 2 * HID));   // (+ the gamma1 snapshot behind them)
   RCCHK(dalloc(e, &e->c_z1, 2 * BH)); RCCHK(dalloc(e, &e->c_xh1, 2 * BH)); RCCHK(dalloc(e, &e->c_h1, 2 * BH)); RCCHK(dalloc(e, &e->c_rs1, 2 * B));
   RCCHK(dalloc(e, &e->c_z2, 2 * BH)); RCCHK(dalloc(e, &e->c_dz2, 2 * BH)); RCCHK(dalloc(e, &e->c_dh1, 2 * BH)); RCCHK(dalloc(e, &e->c_dz1, 2 * BH));

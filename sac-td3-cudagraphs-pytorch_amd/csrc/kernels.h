@@ -2596,7 +2596,23 @@ __global__ __launch_bounds__(16 * RPB) void k_actorq_tail(ActorQTail p) {
 // critic i = blockIdx.z.  Every block evaluates BOTH critics' heads on its rows (the min decides which critic a row's gradient
 // flows through), keeps its own critic's dz2 rows in LDS as the A operand; nothing downstream reads dz2 itself in the actor
 // update, so it is not stored.  Q(s, pi(s)) and the loss partial come from the column-tile-0 blocks.
-struct QtailNn { ActorQTail c; const float* Wt; int ldw; float* dX; int xr; };
+// dQ/da without a launch of its own (B < 1024, narrow heads, ac_dim <= 7).  What k_ln_bwd<16>'s dQ/da form computes per batch row --
+//   dA[j] = sum_c dz1[c] W1[c][o + j],  dz1 = rstd (dxh - m1 - xhat m2),  dxh = relu'(.) dh1 gamma1,  m1 = mean_c dxh,  m2 = mean_c dxh xhat
+// -- is linear in sums over the 256 columns:  dA[j] = rstd (P[j] - m1 S[j] - m2 X[j])  with  P[j] = sum_c dxh[c] W1a[c][j],
+// X[j] = sum_c xhat[c] W1a[c][j],  S[j] = sum_c W1a[c][j]  (W1a = the action columns of W1).  Every column-tile block of k_qtail_nn
+// holds a [16 rows] x [16 NT columns] piece of dh1 when its GEMM is done: wave 0 gates and scales it, turns it round through LDS and
+// gets the block's share of P (and of m1: a column of ones behind W1a) and of X with 4 NT MFMAs each, m2's share with DPP row sums, and
+// stores them as ONE partial per (row, block): ps[net][row][tile][pqw] = P[0 .. a-1], sum dxh, X[0 .. a-1], sum dxh xhat.  The
+// row-block-0 blocks also store their share of S.  k_headbwd_nn sums the tiles in a fixed order and finishes dA.  dh1 itself is not
+// stored any more (nothing else reads it in the actor update).
+struct QaFold {
+  int on, ln, a, pqw, ntile;             // pqw = floats per partial (8: a <= 3, else 16); ntile = column-tile blocks per row block
+  const float* h1; const float* xh1;     // [nq][B][HID]: the critics' layer-1 activations / xhat at (s, pi(s))
+  int g1_off, w1_off, ld1, k_off;        // gamma1 and W1 inside a critic's parameter block, W1's row stride, first action column (= ob_dim)
+  float* ps;                             // [nq][B][ntile][pqw]
+  float* S;                              // [nq][ntile][8]
+};
+struct QtailNn { ActorQTail c; const float* Wt; int ldw; float* dX; int xr; QaFold qa; };
 template <int NT>
 __global__ __launch_bounds__(256) void k_qtail_nn(QtailNn a) {
   const ActorQTail& p = a.c;
@@ -2633,6 +2649,31 @@ __global__ __launch_bounds__(256) void k_qtail_nn(QtailNn a) {
     for (int c = 0; c < 4; ++c) {
       const float* wp = Wc + (long)(16 * c) * a.ldw;
       bv[nt][c] = make_float4(wp[0], wp[a.ldw], wp[2 * (long)a.ldw], wp[3 * (long)a.ldw]);
+    }
+  }
+  // the dQ/da epilogue's operands (wave 0: every 16-column tile of the block)
+  float qh[NT][4], qx[NT][4], qg[NT];
+  float4 qw[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    qg[nt] = 1.f; qw[nt] = f4(0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qh[nt][i] = 1.f; qx[nt][i] = 0.f; }
+  }
+  if (a.qa.on && wave == 0) {
+    const float* Pn = p.P + net * p.p_ns;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = c_lo + 16 * nt + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long o = ((long)net * p.B + min(tm * 16 + 4 * (lane >> 4) + i, p.B - 1)) * HID + col;
+        qh[nt][i] = a.qa.h1[o]; if (a.qa.ln) qx[nt][i] = a.qa.xh1[o];
+      }
+      if (a.qa.ln) qg[nt] = Pn[a.qa.g1_off + col];
+      // B fragments: lane (j = r, kq) holds W1[c_lo + 16 nt + 4 kq + m][k_off + j], m = 0 .. 3 (column clamped; masked once the loads are in)
+      const float* wr = Pn + a.qa.w1_off + (long)(c_lo + 16 * nt + 4 * kq) * a.qa.ld1 + a.qa.k_off + min(r, a.qa.a - 1);
+      qw[nt] = make_float4(wr[0], wr[a.qa.ld1], wr[2 * (long)a.qa.ld1], wr[3 * (long)a.qa.ld1]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -2687,6 +2728,46 @@ __global__ __launch_bounds__(256) void k_qtail_nn(QtailNn a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
   __syncthreads();
+  if (a.qa.on) {                                            // (uniform) the dQ/da partials instead of dh1: see QaFold
+    if (wave != 0) return;
+    const int na = a.qa.a;
+    f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aX = {0.f, 0.f, 0.f, 0.f}, aS = {0.f, 0.f, 0.f, 0.f};
+    float s2r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float* T = red + nt * 4 * 64 * 4;                     // this tile's slab of `red`: read first, then scratch for the two transposes
+      const float4 x0 = ld4(T + lane * 4), x1 = ld4(T + 256 + lane * 4), x2 = ld4(T + 512 + lane * 4), x3 = ld4(T + 768 + lane * 4);
+      const float o[4] = {(x0.x + x1.x) + (x2.x + x3.x), (x0.y + x1.y) + (x2.y + x3.y), (x0.z + x1.z) + (x2.z + x3.z), (x0.w + x1.w) + (x2.w + x3.w)};
+      float4 bw = qw[nt];                                   // lanes j < a: W1a; j == a: ones (the row sum of dxh); else nothing
+      if (r >= na) bw = f4(r == na ? 1.f : 0.f);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the slab has been read before it is overwritten
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dy = qh[nt][i] > 0.f ? o[i] : 0.f;
+        const float dxh = a.qa.ln ? dy * qg[nt] : dy;
+        if (a.qa.ln) s2r[i] += row16_sum(dxh * qx[nt][i]);
+        T[(4 * (lane >> 4) + i) * 20 + (lane & 15)] = dxh;
+        T[320 + (4 * (lane >> 4) + i) * 20 + (lane & 15)] = qx[nt][i];
+      }
+      const float4 fa = ld4(T + r * 20 + 4 * kq), fx4 = ld4(T + 320 + r * 20 + 4 * kq);
+      MFMA4(aP, fa, bw);
+      if (a.qa.ln) { MFMA4(aX, fx4, bw); }
+      if (a.qa.ln && tm == 0) { const float4 one = f4(1.f); MFMA4(aS, one, bw); }
+    }
+    // lane (j = lane & 15, row group lane >> 4): aP[i] = P[j] (j < a) or sum dxh (j == a) of row 4 (lane >> 4) + i, aX[i] = X[j]
+    float* ps = a.qa.ps + (((long)net * p.B) * a.qa.ntile + tk) * a.qa.pqw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int orow = tm * 16 + 4 * (lane >> 4) + i;
+      if (orow >= p.B) continue;
+      float* d = ps + (long)orow * a.qa.ntile * a.qa.pqw;
+      if (r <= na) d[r] = aP[i];
+      if (a.qa.ln && r < na) d[na + 1 + r] = aX[i];
+      if (a.qa.ln && r == 0) d[2 * na + 1] = s2r[i];
+    }
+    if (a.qa.ln && tm == 0 && lane < 16 && r < na) a.qa.S[((long)net * a.qa.ntile + tk) * 8 + r] = aS[0];
+    return;
+  }
   if (wave < NT) {
     const float* rr = red + (wave * 4 * 64 + lane) * 4;
     const float4 x0 = ld4(rr), x1 = ld4(rr + 256), x2 = ld4(rr + 512), x3 = ld4(rr + 768);
@@ -2963,7 +3044,9 @@ __global__ __launch_bounds__(16 * RPB) void k_actor_head_bwd_s(ActorHeadBwd p) {
 // actor's dh1 = dz2 W2.  Every block redoes the head backward of its 16 rows (k_actor_head_bwd_s's arithmetic: lane n of a row
 // computes du[n], DPP row broadcast, nh FMAs per column, LayerNorm backward), keeps the dz2 rows in LDS as the A operand, and
 // stores ITS 16 columns of dz2 and of the two column partials; du comes from the column-tile-0 block.
-struct HeadBwdNn { ActorHeadBwd c; const float* Wt; int ldw; float* dX; int xr; NnFold f; };
+// qa.on: dA is not read but finished here from k_qtail_nn's partials (QaFold): rstd = the critics' layer-1 rstd [nq][B]
+struct QaIn { int on, ln, a, pqw, ntile; const float* ps; const float* S; const float* rstd; float* dA; };
+struct HeadBwdNn { ActorHeadBwd c; const float* Wt; int ldw; float* dX; int xr; NnFold f; QaIn qa; };
 __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
   const ActorHeadBwd& p = a.c;
   constexpr int CB = 16;
@@ -2991,7 +3074,29 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
   const int j0 = min(second ? sub - p.a : sub, p.a - 1);
   const float* tgr = p.tg + (long)bc * 4 * p.a4;
   float la = p.sac ? *p.log_alpha : 0.f;
-  float o_dA = p.dA[(long)bc * p.ldA + j0], o_dA1 = p.nq == 2 ? p.dA[p.dA_ns + (long)bc * p.ldA + j0] : 0.f;
+  float o_dA = 0.f, o_dA1 = 0.f;
+  // (qa.on) the row's partials: thread `sub` takes float4 #sub, #sub + 16, ... of the row's ntile x pqw floats of each critic
+  float4 qv[2] = {f4(0.f), f4(0.f)}, qs[2] = {f4(0.f), f4(0.f)};
+  float qrs[2] = {1.f, 1.f};
+  if (a.qa.on) {
+    const int n4 = a.qa.ntile * a.qa.pqw / 4, s4 = a.qa.ntile * 2;     // float4s per row / of a critic's S partials
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < p.nq) {
+        const float* pr = a.qa.ps + ((long)q * p.B + bc) * (long)n4 * 4;
+        float4 v0 = ld4(pr + 4 * sub), v1 = f4(0.f), v2 = f4(0.f), v3 = f4(0.f);
+        if (n4 > 16) v1 = ld4(pr + 4 * (sub + 16));
+        if (n4 > 32) { v2 = ld4(pr + 4 * (sub + 32)); v3 = ld4(pr + 4 * (sub + 48)); }
+        qv[q] = (v0 + v1) + (v2 + v3);
+        const float* sr = a.qa.S + (long)q * s4 * 4;
+        float4 t0 = ld4(sr + 4 * sub), t1 = f4(0.f);
+        if (s4 > 16) t1 = ld4(sr + 4 * (sub + 16));
+        qs[q] = t0 + t1;
+        if (a.qa.ln) qrs[q] = a.qa.rstd[(long)q * p.B + bc];
+      }
+  } else {
+    o_dA = p.dA[(long)bc * p.ldA + j0]; o_dA1 = p.nq == 2 ? p.dA[p.dA_ns + (long)bc * p.ldA + j0] : 0.f;
+  }
   float o_sc = p.scale[j0], o_t0 = tgr[j0];
   float o_t1 = 0.f, o_t2 = 0.f, o_e = 0.f;
   if (p.sac) { o_t1 = tgr[p.a4 + j0]; o_t2 = tgr[2 * p.a4 + j0]; o_e = p.eps[(long)bc * p.a + j0]; }
@@ -3016,6 +3121,36 @@ __global__ __launch_bounds__(256) void k_headbwd_nn(HeadBwdNn a) {
     if (a.f.ln) fg = p.P[a.f.g1_off + col];
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (a.qa.on) {
+    // sum the tiles: the float4s a thread took all hold the same part of a partial (16 is a multiple of pqw / 4), so lanes with equal
+    // sub mod (pqw / 4) add up (DPP row rotations); lane g < pqw / 4 then parks part g of the row's sums in LDS for the whole row to read
+    float* Vs = red + (row * 2) * 24;                       // [16 rows][2 critics][16 sums | 8 S]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < p.nq) {
+        float v[8] = {qv[q].x, qv[q].y, qv[q].z, qv[q].w, qs[q].x, qs[q].y, qs[q].z, qs[q].w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k >= 4 || a.qa.pqw == 8) v[k] += dpp_mov<0x122>(v[k]);     // row_ror:2 (S partials are 8 floats: parts 0, 1)
+          v[k] += dpp_mov<0x124>(v[k]); v[k] += dpp_mov<0x128>(v[k]);       // row_ror:4, row_ror:8
+        }
+        if (sub < a.qa.pqw / 4) st4(Vs + q * 24 + 4 * sub, make_float4(v[0], v[1], v[2], v[3]));
+        if (sub < 2) st4(Vs + q * 24 + 16 + 4 * sub, make_float4(v[4], v[5], v[6], v[7]));
+      }
+    const int na = a.qa.a;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < p.nq) {
+        const float* V = Vs + q * 24;
+        const float P = V[j0];
+        float dq = P;
+        if (a.qa.ln) dq = (P - V[na] * (1.0f / HID) * V[16 + j0] - V[2 * na + 1] * (1.0f / HID) * V[na + 1 + j0]) * qrs[q];
+        if (a.qa.dA && tk == 0 && valid && sub < na) a.qa.dA[((long)q * p.B + b) * p.ldA + sub] = dq;
+        tot += dq;
+      }
+    o_dA = tot; o_dA1 = 0.f;
+  }
   PIN(la); PIN(o_dA); PIN(o_dA1); PIN(o_sc); PIN(o_t0); PIN(o_t1); PIN(o_t2); PIN(o_e);
   const float dlogp = p.sac ? expf(la) / (float)p.B : 0.f;
   float d;                                        // du[sub]
