@@ -773,7 +773,7 @@ def test_graphs_can_be_instantiated_ahead_of_the_first_step():
         if ahead:
             before = (eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS))
             eng.instantiate_graphs()
-            assert eng.graph_kernel_count(2) == 5 and eng.graph_kernel_count(3) >= 20 and eng.graph_kernel_count(4) > 20
+            assert eng.graph_kernel_count(2) == 5 and eng.graph_kernel_count(3) == 18 and eng.graph_kernel_count(4) == 21
             assert np.array_equal(before[0], eng.get_params(_lib.ACTOR)) and np.array_equal(before[1], eng.get_params(_lib.CRITICS))
         eng.run_iterations(0, 7)
         res.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"]))
@@ -955,9 +955,9 @@ def test_calls_run_on_the_engines_device_whatever_the_current_device_is():
 
 def test_time_nodes_lists_the_iteration_graphs():
     """sactd3_time_nodes walks the same enqueue sequence the graphs are captured from: node counts agree with the
-    instantiated graphs (5 / 20 at Hopper shapes: two launches open the iteration -- sample, gather, next-action pass and the
-    first actor update's policy pass --, three make the critic update, five an actor update, two the temperature draw) and
-    every node has a kernel-instance name, a grid and a time."""
+    instantiated graphs (5 / 18 at Hopper shapes: two launches open the iteration -- sample, gather, next-action pass and the
+    first actor update's policy pass --, three make the critic update, four an actor update, two each temperature draw, one the
+    last temperature step) and every node has a kernel-instance name, a grid and a time."""
     ref, eng, (o, a, bound) = make_pair("sac", "hopper", 256)
     eng.rb_fill_synthetic(2000)
     for i in range(3):
@@ -965,7 +965,7 @@ def test_time_nodes_lists_the_iteration_graphs():
     eng.sync()
     n0, n1 = eng.graph_kernel_count(2), eng.graph_kernel_count(3)
     g0, g1 = eng.time_nodes(False, 5), eng.time_nodes(True, 5)
-    assert (len(g0), len(g1)) == (n0, n1) == (5, 20)
+    assert (len(g0), len(g1)) == (n0, n1) == (5, 18)
     for n in g0 + g1:
         assert n["name"].startswith("k_") and ":" in n["name"] and n["threads"] > 0 and 0.0 < n["us"] < 1e4
     assert sum(n["flops"] for n in g0) > 0.3e9      # (critic update of SURVEY 8d: A + 8C per sample at B = 256)
