@@ -24,7 +24,7 @@ from collections import defaultdict
 
 # kernels (by name prefix) with 4-byte strided global loads beside their dwordx4 ones; every other k_* kernel of csrc/kernels.h
 # fetches with float4 (global_load_dwordx4) only -- tests/test_abi.py::test_fetch_width_table_matches_the_code_objects checks the ISA (share of non-dwordx4 load bytes)
-MIXED = ("k_nn", "k_actor_head_bwd", "k_ln_bwd<16>")        # exact instance names (no template arguments = a plain kernel)
+MIXED = ("k_nn", "k_actor_head_bwd", "k_ln_bwd<16>", "k_qtail_nn<2>")   # exact instance names; k_qtail_nn<2>: W2 / W1 fragments and the dQ/da epilogue's layer-1 operands are dword loads (32 % of its load bytes)        # exact instance names (no template arguments = a plain kernel)
 
 
 def fetch_factor(kernel):
