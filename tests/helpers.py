@@ -2,7 +2,11 @@
 import numpy as np
 import torch
 
-DIMS = {"hopper": (11, 3, 1.0), "halfcheetah": (17, 6, 1.0), "humanoid": (376, 17, 0.4)}
+DIMS = {"hopper": (11, 3, 1.0), "halfcheetah": (17, 6, 1.0), "humanoid": (376, 17, 0.4),
+        # not environments of BASELINE.json: shapes that take the remaining branches of the narrow-head kernels (4 actions under SAC:
+        # an 8-wide head with 16-float dQ/da partials in 8 tiles; 2 actions under TD3: 8-float partials in 16 tiles; 7 actions: the widest
+        # action vector the folded dQ/da takes)
+        "sac4": (9, 4, 1.0), "td3_2": (5, 2, 2.0), "td3_7": (13, 7, 1.0)}
 
 
 def synth_transitions(n, o, a, bound, seed=0):

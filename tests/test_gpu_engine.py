@@ -234,7 +234,9 @@ CASES = [("sac", "hopper", 256, True), ("sac", "hopper", 40, False), ("td3", "ha
          ("sac", "hopper", 1024, True), ("sac", "humanoid", 1024, False),
          # more than one 256-row slab below B = 1024: the fused row + GEMM launches with a ragged last row block, and k_tn's folded
          # LayerNorm backward across two slabs (the second one partly masked)
-         ("sac", "hopper", 300, True), ("td3", "halfcheetah", 512, True)]
+         ("sac", "hopper", 300, True), ("td3", "halfcheetah", 512, True),
+         # the other shapes of the dQ/da partials (helpers.DIMS)
+         ("sac", "sac4", 128, True), ("td3", "td3_2", 64, True), ("td3", "td3_7", 256, False)]
 
 
 @pytest.mark.parametrize("algo,env,B,ln", CASES)
