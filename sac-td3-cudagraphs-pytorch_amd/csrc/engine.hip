@@ -258,6 +258,18 @@ static void launch_nt_f1(hipStream_t s, int ks, int nt, dim3 grid, const NtArgs&
   else if (c1 == 2) launch_nt_ks<PRO, true, 2>(s, ks, grid, g);
   else launch_nt_ks<PRO, true, 4>(s, ks, grid, g);
 }
+static void launch_nt_c4(hipStream_t s, int nt, dim3 grid, const NtArgs& g) {      // (LayerNorm form, fused first layer, KS = 2 with KS = 4's sums)
+  const int c1 = (g.K1 + 15) / 16;
+  if (nt == 2) {
+    if (c1 <= 1) hipLaunchKernelGGL((k_nt<1, true, 2, 1, 2, true>), grid, dim3(256), 0, s, g);
+    else if (c1 == 2) hipLaunchKernelGGL((k_nt<1, true, 2, 2, 2, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_nt<1, true, 2, 4, 2, true>), grid, dim3(256), 0, s, g);
+  } else {
+    if (c1 <= 1) hipLaunchKernelGGL((k_nt<1, true, 2, 1, 1, true>), grid, dim3(256), 0, s, g);
+    else if (c1 == 2) hipLaunchKernelGGL((k_nt<1, true, 2, 2, 1, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_nt<1, true, 2, 4, 1, true>), grid, dim3(256), 0, s, g);
+  }
+}
 // XCD row groups for xcd_tile (kernels.h) of an R x C tile grid whose row operand is A bytes and column operand W bytes: the
 // split xr x xc = 8 with the least total fetch xc A + xr W among those that divide the grid; 0 = keep row-major numbering.
 static int pick_xr(const sactd3_engine* e, int R, int C, double A, double W) {
@@ -290,11 +302,18 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     int ks = tiles >= 2 * e->num_cus ? 2 : 4;   // measured on 256 .. 4096-tile launches (KS = 1 never won)
     if (e->tune_ks) ks = e->tune_ks;
     if (force_ks) ks = force_ks;
+    // a launch that must reproduce the KS = 4 sums (force_ks: the run-ahead passes of a period graph) but holds several groups: 32-row
+    // blocks with the KS = 4 summation tree (k_nt's C4 form) -- half as many blocks fetch W1 and their W2 tile
+    const bool c4 = force_ks == 4 && fuse1 && pro == 1 && tiles >= 2 * e->num_cus && !(e->tune_rows4 & 32768);
+    if (c4) ks = 2;
     const int rb = 64 / ks;
     // two column tiles per block when the launch would otherwise put two rounds of blocks on every CU: the fused first
     // layer is then recomputed (or the A rows fetched and normalised) by half as many blocks
     int nt = (ks == 2 && ((g.M + rb - 1) / rb) * tiles_n * nets >= 2 * e->num_cus && tiles_n % 2 == 0) ? 2 : 1;
-    if (e->tune_nt == 1 || force_ks) nt = 1;
+    if (e->tune_nt == 1 || (force_ks && !c4)) nt = 1;
+    // (C4: two column tiles per block only when that leaves at most one block per CU: 4 groups -> 256 blocks; 5 groups would be 320,
+    //  a quarter of the CUs with two -- they take 640 single-tile blocks instead)
+    if (c4 && nt == 2 && ((g.M + rb - 1) / rb) * (tiles_n / 2) * nets > e->num_cus) nt = 1;
     NtArgs gg = g;
     gg.nt_blocks = ((g.M + rb - 1) / rb) * (tiles_n / nt);
     // unfused launches read whole input rows: place the tiles so that an XCD pulls few rows and few weight columns (the fused
@@ -306,10 +325,11 @@ static int launch_nt(sactd3_engine* e, hipStream_t s, const char* name, int pro,
     char inst[64] = "k_nt";
     if (e->node_log) {
       const int c1 = (g.K1 + 15) / 16;
-      snprintf(inst, sizeof(inst), "k_nt<%d,%s,%d,%d,%d>.%s", pro, fuse1 ? "true" : "false", ks, fuse1 ? (c1 <= 1 ? 1 : (c1 == 2 ? 2 : 4)) : 0, nt, name);
+      snprintf(inst, sizeof(inst), c4 ? "k_nt<%d,%s,%d,%d,%d,true>.%s" : "k_nt<%d,%s,%d,%d,%d>.%s", pro, fuse1 ? "true" : "false", ks, fuse1 ? (c1 <= 1 ? 1 : (c1 == 2 ? 2 : 4)) : 0, nt, name);
     }
     if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
-    if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, nt, grid, gg); else launch_nt_f1<2>(s, ks, nt, grid, gg); }
+    if (c4) launch_nt_c4(s, nt, grid, gg);
+    else if (fuse1) { if (pro == 1) launch_nt_f1<1>(s, ks, nt, grid, gg); else launch_nt_f1<2>(s, ks, nt, grid, gg); }
     else if (nt == 2) {   // (KS == 2) the A rows are fetched and normalised by half as many blocks
       if (pro == 1) hipLaunchKernelGGL((k_nt<1, false, 2, 0, 2>), grid, dim3(256), 0, s, gg);
       else hipLaunchKernelGGL((k_nt<2, false, 2, 0, 2>), grid, dim3(256), 0, s, gg);

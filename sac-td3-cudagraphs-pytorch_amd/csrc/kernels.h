@@ -559,15 +559,26 @@ __device__ __forceinline__ void riding_gather(const NtArgs& p, int x) {
 // fully coalesced loads, parked in LDS and shared by the block's waves.
 // NT = 16-column tiles per block: 2 halves the number of blocks that recompute the fused first layer (4-net launches, where
 // NT = 1 means two rounds of blocks per CU)
-template <int PRO, bool FUSE1, int KS, int C1, int NT = 1>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
+// C4 (KS == 2 only): 32 rows per block with the SUMMATION TREE of the KS = 4 form -- every wave treats its 8 k chunks as the two
+// groups of 4 that two waves of a KS = 4 block would hold (row statistics: two (mean, M2) partials per lane; second layer: two
+// partial accumulators per wave, summed across the block in the KS = 4 order), so its results are bit-identical to a KS = 4
+// launch of the same rows.  The run-ahead launches of a period graph (up to 5 groups: 1 280 blocks of 16 rows, each fetching the
+// whole of W1 and a W2 tile) use it: they must reproduce, bit for bit, what the single-net KS = 4 launches of those passes compute.
+template <int PRO, bool FUSE1, int KS, int C1, int NT = 1, bool C4 = false>      // C1 = 16-wide k chunks of the fused first layer (1, 2 or 4)
 __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
-  constexpr int RB = 64 / KS, CW = 16 / KS, NP = 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
+  static_assert(!C4 || (KS == 2 && PRO == 1), "C4: the KS = 2 LayerNorm form only");
+  constexpr int RB = 64 / KS, CW = 16 / KS, NP = C4 ? 16 : 4 * KS, SS = 2 * NP + 4;   // rows/block, k chunks/wave, stat partials/row
   constexpr int W1S = 16 * (C1 > 0 ? C1 : 1) + 4;                           // LDS row stride of W1 (K1 <= 16 C1)
   __shared__ __attribute__((aligned(16))) float W2s[NT * 16 * AS];
   __shared__ __attribute__((aligned(16))) float W1s[FUSE1 ? HID * W1S : 4];
   __shared__ __attribute__((aligned(16))) float vec[3 * HID];               // b1 | gamma | beta
   __shared__ __attribute__((aligned(16))) float stat[RB * SS];
-  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NT * 4 * 64 * 4 : 4];
+  // the cross-wave sums of the second layer go where W1 was (fused form: W1 is dead behind the first layer, a barrier ago): the
+  // 5-group run-ahead launch needs 3 blocks per CU to be one round, and 52 KB + the riders' arrays is a few hundred bytes too many
+  constexpr int RED = KS > 1 ? (C4 ? 2 : 1) * NT * 4 * 64 * 4 : 4;
+  static_assert(!FUSE1 || RED <= HID * W1S, "red fits W1's slab");
+  __shared__ __attribute__((aligned(16))) float red_own[FUSE1 ? 4 : RED];
+  float* red = FUSE1 ? W1s : red_own;
   BLK_MARK_K(1, 0);
   if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
     const int x = (int)blockIdx.x - p.nt_blocks;
@@ -686,17 +697,22 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   float rstd = 1.f;
   if (PRO == 1) {
     // this lane holds 4 CW of the row's 256 values; combine the NP (mean, M2) partials of the row (Chan et al.)
-    constexpr float nl = 4.0f * CW;
-    float ml = 0.f;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) ml += sum4(av[c]);
-    ml *= (1.0f / nl);
-    float m2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) { const float4 d = av[c] - f4(ml); m2 += dot4(d, d); }
+    constexpr int CG = C4 ? 4 : CW;                          // chunks per (mean, M2) partial
+    constexpr float nl = 4.0f * CG;
     float* srow = stat + (16 * mt + r) * SS;
-    srow[2 * (ks * 4 + kq)] = ml;
-    srow[2 * (ks * 4 + kq) + 1] = m2;
+#pragma unroll
+    for (int h = 0; h < CW / CG; ++h) {
+      float ml = 0.f;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) ml += sum4(av[CG * h + c]);
+      ml *= (1.0f / nl);
+      float m2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) { const float4 d = av[CG * h + c] - f4(ml); m2 += dot4(d, d); }
+      const int slot = (C4 ? 2 * ks + h : ks) * 4 + kq;      // (C4: the slot of wave 2 ks + h of a KS = 4 block)
+      srow[2 * slot] = ml;
+      srow[2 * slot + 1] = m2;
+    }
     __syncthreads();
     float4 sp[NP / 2];
 #pragma unroll
@@ -746,45 +762,58 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   // Even chunks accumulate in a0, odd ones in a1 (per column tile): 2 NT independent MFMA chains, issued alternately, with the W
   // fragments of four chunks requested together -- no instruction waits for the LDS read or the MFMA right in front of it.  (Each
   // accumulator still sees its chunks in the same order: the sums are bit-identical to the chunk-by-chunk loop this replaces.)
-  f32x4 acc[NT];
+  // C4: one (a0, a1) pair per group of four chunks -- the partial sums two waves of a KS = 4 block would hold.
+  constexpr int NH = C4 ? 2 : 1;                              // partial sums per wave and column tile
+  f32x4 acc[NT], ph[NT][NH];
   {
     constexpr int GC = CW < 4 ? CW : 4;
-    f32x4 a0[NT], a1[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { a0[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int h = 0; h < NH; ++h) {
+      f32x4 a0[NT], a1[NT];
 #pragma unroll
-    for (int c0 = 0; c0 < CW; c0 += GC) {
-      float4 wv[NT][GC];
+      for (int nt = 0; nt < NT; ++nt) { a0[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int c0 = h * (CW / NH); c0 < (h + 1) * (CW / NH); c0 += GC) {
+        float4 wv[NT][GC];
 #pragma unroll
-        for (int j = 0; j < GC; ++j) wv[nt][j] = ld4(W2s + (16 * nt + r) * AS + kb + 16 * (c0 + j));
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int j = 0; j < GC; j += 2)
+          for (int j = 0; j < GC; ++j) wv[nt][j] = ld4(W2s + (16 * nt + r) * AS + kb + 16 * (c0 + j));
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < GC; j += 2)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            a0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j], q), f4c(wv[nt][j], q), a0[nt], 0, 0, 0);
-            if (j + 1 < GC) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j + 1], q), f4c(wv[nt][j + 1], q), a1[nt], 0, 0, 0);
-          }
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              a0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j], q), f4c(wv[nt][j], q), a0[nt], 0, 0, 0);
+              if (j + 1 < GC) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[c0 + j + 1], q), f4c(wv[nt][j + 1], q), a1[nt], 0, 0, 0);
+            }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { ph[nt][h][0] = a0[nt][0] + a1[nt][0]; ph[nt][h][1] = a0[nt][1] + a1[nt][1]; ph[nt][h][2] = a0[nt][2] + a1[nt][2]; ph[nt][h][3] = a0[nt][3] + a1[nt][3]; }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { acc[nt][0] = a0[nt][0] + a1[nt][0]; acc[nt][1] = a0[nt][1] + a1[nt][1]; acc[nt][2] = a0[nt][2] + a1[nt][2]; acc[nt][3] = a0[nt][3] + a1[nt][3]; }
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = ph[nt][0];
   }
   STAMP(3); BLK_PH_K(1, 3);
-  if (KS > 1) {                               // sum the KS K-slices of each 16 x 16 tile; the ks == 0 wave keeps the total
+  if (KS > 1) {                               // sum the K-slices of each 16 x 16 tile in slice order; the ks == 0 wave keeps the total
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) st4(red + ((nt * 4 + wave) * 64 + lane) * 4, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        st4(red + (((nt * 4 + wave) * NH + h) * 64 + lane) * 4, make_float4(ph[nt][h][0], ph[nt][h][1], ph[nt][h][2], ph[nt][h][3]));
     __syncthreads();
     if (ks == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 1; j < KS; ++j) {
-          const float4 o = ld4(red + ((nt * 4 + wave + j) * 64 + lane) * 4);
-          acc[nt][0] += o.x; acc[nt][1] += o.y; acc[nt][2] += o.z; acc[nt][3] += o.w;
-        }
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if (j == 0 && h == 0) continue;                   // (the sum starts from this wave's first partial)
+            const float4 o = ld4(red + (((nt * 4 + wave + j) * NH + h) * 64 + lane) * 4);
+            acc[nt][0] += o.x; acc[nt][1] += o.y; acc[nt][2] += o.z; acc[nt][3] += o.w;
+          }
     }
   }
   STAMP(4); BLK_PH_K(1, 4);
