@@ -505,7 +505,9 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   // end of the grid do the k_gather copy into the batch slot for the later kernels -- the gather leaves the critical path.  Up to three
   // gathers ride (gb_each blocks each: the samples of the two critic-only iterations of a period and of the NEXT period's first
   // iteration, into their own batch slots).
-  int nt_blocks; int gblocks; int gb_each; GatherArgs ga[3];
+  int nt_blocks; int gblocks; int gb_each;
+  int flat, flat_r, flat_n;              // (below: NtArgs::flat) nets, rider slots (padded), riders -- beside nt_blocks: one scalar-cache line
+  GatherArgs ga[3];
   // a second step counter + Adam scalars (a launch that opens the critic AND the actor update): done by thread 64 of block 0
   int* tick0b; float* adam_out_b; double* adam_pw_b; float lr_b;
   int xr;                                // XCD row-block groups of the tile placement (xcd_tile; unfused launches), 0 = row-major numbering
@@ -515,6 +517,11 @@ struct NtArgs {              // Y[M,N] = pro(A)[M,K] * W[N,K]^T + bias ; block =
   int alpha_block; AlphaArgs al;
   // ... and the noise draws of the actor tail that follows this launch (see NoiseJob): nz_n jobs, nz[i].blocks blocks each
   int nz_n; NoiseJob nz[5]; const DevCtl* nz_ctl;
+  // flat > 0 (k_nt, launches of several nets that carry riders): a 1-D grid -- flat_r rider slots FIRST (a multiple of 8: the tiles keep
+  // their XCDs; riders are the long latency chains of a launch, gathers out of a cold ring, and should start at once), then flat x
+  // nt_blocks tile blocks, net-major.  In the 3-D grid every net gets the riders' x slots (empty blocks for net > 0), and a 4-net
+  // launch of exactly one block per CU then has 260 blocks: four CUs run two TILE blocks side by side and finish 2 us after the rest;
+  // here the blocks that share a CU share it with a rider that is gone after a microsecond or two (fields: beside nt_blocks)
 };
 
 // Sum the 4 waves' accumulators of a block (split-K); the total is returned in wave 0.  Contains a barrier.
@@ -580,18 +587,25 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   __shared__ __attribute__((aligned(16))) float red_own[FUSE1 ? 4 : RED];
   float* red = FUSE1 ? W1s : red_own;
   BLK_MARK_K(1, 0);
-  if ((p.gblocks || p.alpha_block || p.nz_n) && (int)blockIdx.x >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
-    const int x = (int)blockIdx.x - p.nt_blocks;
-    if (x < p.gblocks) { if (blockIdx.z == 0) riding_gather(p, x); }
-    else if (blockIdx.z != 0) { }
+  int bx = blockIdx.x, net = blockIdx.z;                      // tile block within the net / net (3-D grid)
+  bool rider_net0 = blockIdx.z == 0;
+  if (p.flat) {                                               // 1-D grid: flat_r rider slots, then flat x nt_blocks tile blocks
+    rider_net0 = true;
+    if (bx < p.flat_r) { if (bx >= p.flat_n) return; bx += p.nt_blocks; net = 0; }      // (padding slots exit)
+    else { bx -= p.flat_r; net = small_div(bx, p.nt_blocks); bx -= net * p.nt_blocks; }
+  }
+  if ((p.gblocks || p.alpha_block || p.nz_n) && bx >= p.nt_blocks) {   // block-uniform: replay gather / temperature step / noise
+    const int x = bx - p.nt_blocks;
+    if (x < p.gblocks) { if (rider_net0) riding_gather(p, x); }
+    else if (!rider_net0) { }
     else riding_body(p, x - p.gblocks);
     BLK_MARK_K(1, 1);
     return;
   }
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, net = blockIdx.z;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const int mt = wave / KS, ks = wave % KS;
-  if (blockIdx.x == 0 && net == 0) {
+  if (bx == 0 && net == 0) {
     if (t == 0 && (p.tick0 || p.tick1)) tick_all(p.tick0, p.tick1, p.adam_pw, p.adam_out, p.lr, p.b1, p.b2);
     if (t == 64 && p.tick0b) tick_all(p.tick0b, nullptr, p.adam_pw_b, p.adam_out_b, p.lr_b, p.b1, p.b2);
   }
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(256) void k_nt(NtArgs p) {
   const float* Pn = G.P + ni * p.p_ns;
   const int tiles_n = (p.N + 16 * NT - 1) / (16 * NT);
   int tmb, tn;
-  xcd_tile(blockIdx.x, (p.M + RB - 1) / RB, tiles_n, FUSE1 ? 0 : p.xr, tmb, tn);
+  xcd_tile(bx, (p.M + RB - 1) / RB, tiles_n, FUSE1 ? 0 : p.xr, tmb, tn);
   const int m0 = tmb * RB + 16 * mt, n0 = tn * 16 * NT;          // this wave's rows / the block's columns
   const int mrow = min(m0 + r, p.M - 1);
   const int kb = (ks * CW) * 16 + 4 * kq;                    // first k of this lane's fragments

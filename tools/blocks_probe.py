@@ -8,7 +8,8 @@ os.environ["SACTD3_LIBRARY"] = os.path.join(ROOT, "sac-td3-cudagraphs-pytorch_am
 import numpy as np
 import bench
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "hopper_sac"]
-which = 1 if len(sys.argv) > 2 and sys.argv[2] in ("nt", "ntp") else 0
+which = 1 if len(sys.argv) > 2 and sys.argv[2] in ("nt", "ntp", "ntr") else 0
+rider = len(sys.argv) > 2 and sys.argv[2] == "ntr"      # a cut-short period of 2 iterations: its last trunk launch carries the deferred temperature step
 period = len(sys.argv) > 2 and sys.argv[2] == "ntp"     # a whole period: the run-ahead trunk launch survives in the block ids the critic trunks do not reach
 names = (["descriptor + decode", "operands landed", "mfma done", "reduced", "committed"],
          ["descriptor + decode", "operands parked", "layer 1 + LN", "layer-1 stores", "layer 2", "reduced", "stored"])[which]
@@ -21,7 +22,9 @@ lib.sactd3_debug_blocks_select.argtypes = [C.c_void_p, C.c_int]
 n = 1600
 for rep in range(3):
     assert lib.sactd3_debug_blocks_select(eng._h, which) == 0
-    if period:
+    if rider:
+        eng.step_period(); eng.sync(); assert lib.sactd3_debug_blocks_select(eng._h, which) == 0; eng.step_prefix(2); eng.sync()
+    elif period:
         eng.step_period(); eng.sync()
     else:
         eng.step(False); eng.step(False); eng.sync()      # the last stamped launch of the family = the second iteration's
