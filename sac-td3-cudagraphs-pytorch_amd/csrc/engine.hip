@@ -487,6 +487,16 @@ static TnProb tn_prob(const float* dY, int ldy, long dy_ns, int N, const float* 
   q.w_off = w_off; q.ldw = ldw; q.b_off = b_off; q.nfin = 0; q.fin_s_off = -1;
   return q;
 }
+// Rows [n_lo, n_lo + n) of a weight-gradient problem as a problem of its own (the same GEMM, cut along dW's rows).  A launch with a
+// folded layer-1 problem puts it BETWEEN two such pieces of the W2 problem: a launch of 300 blocks gives the first ~50 CUs a second
+// block (ids 256 ..), and the folded blocks -- 80 KB of operands, the launch's long pole -- must not be among the first ~50 ids (the
+// critics' net-0 ones were: 6.8 us against net 1's 6.1, tools/blocks_probe.py).  Vector finalisations stay with the first piece.
+static TnProb tn_rows(const TnProb& q, int n_lo, int n) {
+  TnProb r = q;
+  r.dY = q.dY + n_lo; r.N = n; r.w_off = q.w_off + n_lo * q.ldw; r.b_off = q.b_off >= 0 ? q.b_off + n_lo : -1;
+  if (n_lo) { r.nfin = 0; r.fin_s_off = -1; }
+  return r;
+}
 static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin] = off; q.fin_nblk[q.nfin++] = nblk; }
 
 // The two hidden layers of MLP trunks: z2 = relu(LN(x W1^T + b1)) W2^T + b2 for up to two groups of nets
@@ -827,7 +837,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
      //   dW2 = dz2^T h1, db2, dgamma2, dbeta2, dWhead, dbhead ; dW1 = dz1^T [s|a], db1, dgamma1, dbeta1
     TnArgs g{};
     g.nprob = 2; g.M = B; g.G = e->Gc; g.g_ns = e->Lc.size;
-    const int i2 = fold_ln1 ? 1 : 0, i1 = 1 - i2;      // the folded layer-1 problem's blocks carry more: they go first
+    const int i2 = 0, i1 = fold_ln1 ? 2 : 1;           // folded: [W2 rows 0 .. 127][layer 1][W2 rows 128 .. 255] (tn_rows)
     g.pr[i2] = tn_prob(e->c_dz2, HID, BH, HID, e->c_h1, HID, BH, HID, e->Lc.W2, HID, e->Lc.b2);
     const int nb_tail = (!fused_tail_nn && (e->tune_rows4 & 1)) ? e->nblk4 : e->nblk, nb_ln = (e->tune_rows4 & 2) ? e->nblk4 : e->nblk;   // row blocks that wrote the partials
     if (ln) { tn_fin(g.pr[i2], 0, e->Lc.g2, nb_tail); tn_fin(g.pr[i2], 1, e->Lc.be2, nb_tail); }
@@ -837,6 +847,7 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       TnProb& q = g.pr[i1];
       q.fold = 1; q.f_ln = ln; q.f_g_off = e->Lc.g1; q.f_be_off = e->Lc.be1; q.f_xh = e->c_xh1; q.f_rstd = e->c_rs1; q.f_ps = e->c_ps; q.f_dz = e->c_dz1; q.f_g = e->c_ps + 2L * B * PS_W;
     } else if (ln) { tn_fin(g.pr[i1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[i1], 4, e->Lc.be1, nb_ln); }
+    if (fold_ln1) { g.nprob = 3; g.pr[1] = tn_rows(g.pr[0], HID / 2, HID / 2); g.pr[0] = tn_rows(g.pr[0], 0, HID / 2); std::swap(g.pr[1], g.pr[2]); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;
@@ -977,7 +988,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
      //   dWhead = du^T h2, dbhead ; dW2 = dz2^T h1, db2, dgamma2, dbeta2 ; dW1 = dz1^T s, db1, dgamma1, dbeta1
     TnArgs g{};
     g.nprob = 3; g.M = B; g.G = e->Ga; g.g_ns = 0;
-    const int ih = fold_ln1 ? 1 : 0, i2 = ih + 1, i1 = fold_ln1 ? 0 : 2;   // the folded layer-1 problem's blocks carry more: they go first
+    const int ih = 0, i2 = 1, i1 = fold_ln1 ? 3 : 2;      // folded: [head][W2 rows 0 .. 47][layer 1][W2 rows 48 .. 255] (tn_rows)
     g.pr[ih] = tn_prob(e->a_du, e->ldu, 0, e->nh, e->a_h2, HID, 0, HID, e->La.Wh, HID, e->La.bh);
     g.pr[i2] = tn_prob(e->a_dz2, HID, 0, HID, e->a_h1, HID, 0, HID, e->La.W2, HID, e->La.b2);
     const int nb_head = (small_head && !fused_head_nn) ? e->nblk4 : e->nblk;      // row blocks that wrote the head backward's column partials
@@ -987,6 +998,7 @@ static int enqueue_update_actor(sactd3_engine* e, hipStream_t s, int j, bool hea
       TnProb& q = g.pr[i1];
       q.fold = 1; q.f_ln = ln; q.f_g_off = e->La.g1; q.f_be_off = e->La.be1; q.f_xh = e->a_xh1; q.f_rstd = e->a_rs1; q.f_ps = e->a_ps; q.f_dz = e->a_dz1; q.f_g = e->a_ps + (long)B * PS_W;
     } else if (ln) { tn_fin(g.pr[i1], 3, e->La.g1, e->nblk); tn_fin(g.pr[i1], 4, e->La.be1, e->nblk); }
+    if (fold_ln1) { g.nprob = 4; g.pr[2] = tn_rows(g.pr[1], 48, HID - 48); g.pr[1] = tn_rows(g.pr[1], 0, 48); std::swap(g.pr[2], g.pr[3]); }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = clip ? 0 : 1; g.P = e->Pa; g.Mo = e->Ma; g.Vo = e->Va; g.T = clip ? nullptr : polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_a;
     if (td3 && g.T && (ahead > 0 || chain_slot >= 0)) { g.T2 = e->Ta2; g.T3 = e->Ta3; }   // the actor target of the next two Polyak updates, now

@@ -1436,8 +1436,8 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   const float* f_g;                      // [nets][HID]: gamma1 as the producer saw it (the k-tile-0 blocks of THIS launch step the live one)
 };
 constexpr int PS_W = 32;                 // floats per row of the row-sum partials: 16 tiles x 2 sums
-struct TnArgs {              // up to 3 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
-  TnProb pr[3]; int nprob; int M;
+struct TnArgs {              // up to 4 problems per launch; block = one 16 x 16 tile of one problem, M split over the 4 waves
+  TnProb pr[4]; int nprob; int M;       // (a GEMM may be cut in two problems to steer which blocks share a CU: engine.hip, tn_split)
   float* G; long g_ns;                   // gradient arena (always written; net stride g_ns)
   // optimiser step fused into the epilogue (torch.optim.Adam, agents/agent.py:236,286), optionally with the Polyak
   // update of the same element (agents/agent.py:328).  apply == 0: gradients only (clip_grad_norm_ path).
@@ -1508,6 +1508,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   int pi = 0;
   if (p.nprob > 1 && (int)blockIdx.x >= p.pr[1].tile0) pi = 1;
   if (p.nprob > 2 && (int)blockIdx.x >= p.pr[2].tile0) pi = 2;
+  if (p.nprob > 3 && (int)blockIdx.x >= p.pr[3].tile0) pi = 3;
   const TnProb q = p.pr[pi];     // ONE batch of scalar loads for the whole problem (field-by-field they came in 3-4 dependent rounds)
   const int local = blockIdx.x - q.tile0;
   const int tiles_k = (((q.ldw + 15) >> 4) + KT - 1) / KT;
