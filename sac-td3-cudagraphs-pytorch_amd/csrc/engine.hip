@@ -445,7 +445,7 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   double fl = 0.0, by = 0.0;
   for (int i = 0; i < g.nprob; ++i) {
     fl += 2.0 * nets * (double)g.M * g.pr[i].N * g.pr[i].K;
-    by += 4.0 * nets * (double)g.M * (g.pr[i].N + g.pr[i].K) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
+    by += 4.0 * nets * (double)g.M * (g.pr[i].N + (g.pr[i].x_dup ? 0 : g.pr[i].K)) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
   }
   bool fold = false;
   for (int i = 0; i < g.nprob; ++i) fold = fold || g.pr[i].fold;
@@ -494,7 +494,7 @@ static TnProb tn_prob(const float* dY, int ldy, long dy_ns, int N, const float* 
 static TnProb tn_rows(const TnProb& q, int n_lo, int n) {
   TnProb r = q;
   r.dY = q.dY + n_lo; r.N = n; r.w_off = q.w_off + n_lo * q.ldw; r.b_off = q.b_off >= 0 ? q.b_off + n_lo : -1;
-  if (n_lo) { r.nfin = 0; r.fin_s_off = -1; }
+  if (n_lo) { r.nfin = 0; r.fin_s_off = -1; r.x_dup = 1; }
   return r;
 }
 static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin] = off; q.fin_nblk[q.nfin++] = nblk; }

@@ -1431,6 +1431,7 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   // left them as one partial per 16-column tile (f_ps[net][row][0:16] = sum dy g, [16:32] = sum dy g xhat), summed here in
   // a fixed order.  The k-tile-0 blocks also own dgamma1 / dbeta1 of their 16 columns (column sums of dy xhat and dy over the
   // batch) and keep dz1 readable (f_dz).  f_ln == 0: no LayerNorm, dz1 = dy.
+  int x_dup;                             // host-side bookkeeping: a later row piece of a cut problem (tn_rows): its X operand is already counted
   int fold, f_ln, f_g_off, f_be_off;
   const float* f_xh; const float* f_rstd; const float* f_ps; float* f_dz;    // [nets][M][HID], [nets][M], [nets][M][32], [nets][M][HID]
   const float* f_g;                      // [nets][HID]: gamma1 as the producer saw it (the k-tile-0 blocks of THIS launch step the live one)
