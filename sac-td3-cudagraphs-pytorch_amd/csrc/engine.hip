@@ -856,7 +856,9 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
     const bool rides = actor_targ_rides && !(B >= BIG_BATCH && e->Gp);       // (the split-M route has no riding blocks)
     if (rides) {
       g.pk.t0 = e->Ta; g.pk.p0 = e->Pa; g.pk.n0 = e->La.size; g.pk.tau = c.polyak;
-      g.pk_blocks = (int)std::min<long>(64, (e->La.size / 4 + 255) / 256);
+      // (few of them: the launch already has more blocks than the chip has CUs, and every extra one lands beside a tile block --
+      //  64 riding blocks instead of 8: +0.8 us per TD3 iteration)
+      g.pk_blocks = (int)std::min<long>(8, (e->La.size / 4 + 255) / 256);
       if (actor_targ_done) *actor_targ_done = true;
     }
     RCCHK(launch_tn(e, s, fused_polyak_targ ? (rides ? "dW+adam+polyak & actor-target polyak" : "dW+adam+polyak") : "dW+adam", g, 2, ctr_owed));
