@@ -100,3 +100,39 @@ def test_batch_handle_goes_stale_when_the_slot_is_refilled():
     with pytest.raises(P.StaleBatchError):
         second["observations"]                                 # never read while current: its rows are gone
     assert float(third["rewards"][0, 0]) == 3.0
+
+
+@pytest.mark.parametrize("delay,td3,freq", [(2, False, 1), (2, True, 1), (1, False, 1), (2, False, 2), (0, False, 1)])
+def test_run_iterations_splits_a_run_into_periods_a_cut_short_period_and_single_iterations(delay, td3, freq):
+    """Engine.run_iterations (the loop body of orchestrator.py:337-352 for n iterations): whole periods of the actor schedule as one
+    launch each, what is left behind the last whole period as ONE cut-short period (sactd3_step_prefix), iterations in front of the
+    first period boundary one by one; no period graphs when the target update is gated (SAC with crit_targ_update_freq != 1) or
+    there is no actor schedule (delay 0).  The launch sequence always covers exactly iterations i0 .. i0 + n - 1, actor updates at
+    the multiples of delay + 1."""
+    from sac_td3_cudagraphs_pytorch_amd.engine import Engine
+    period = delay + 1
+    can = delay > 0 and (td3 or freq == 1)
+    for i0 in range(0, 7):
+        for n in range(0, 11):
+            calls = []
+            stub = SimpleNamespace(cfg=SimpleNamespace(actor_update_delay=delay, prefer_td3_over_sac=td3, crit_targ_update_freq=freq),
+                                   step=lambda a: calls.append(("step", bool(a))), step_period=lambda: calls.append(("period",)),
+                                   step_prefix=lambda m: calls.append(("prefix", m)))
+            assert Engine.run_iterations(stub, i0, n) == i0 + n
+            i = i0
+            for c in calls:                                     # replay the launches: which iterations, which of them with actor updates
+                if c[0] == "period":
+                    assert can and i % period == 0
+                    i += period
+                elif c[0] == "prefix":
+                    assert can and i % period == 0 and 1 <= c[1] <= delay and c is calls[-1]
+                    i += c[1]
+                else:
+                    assert c[1] == (i % period == 0)
+                    i += 1
+            assert i == i0 + n
+            if can:                                             # nothing that could have been a period or a cut-short period went out singly
+                assert not any(c[0] == "step" and c[1] for c in calls)
+                assert sum(c[0] == "period" for c in calls) == max(0, (i0 + n) // period - (i0 + period - 1) // period)      # every whole period inside the run
+            else:
+                assert all(c[0] == "step" for c in calls)
