@@ -673,7 +673,7 @@ def test_fused_step_equals_api_sequence(algo, env, B):
 
 
 @pytest.mark.parametrize("algo,env,B", [("sac", "hopper", 256), ("td3", "halfcheetah", 256), ("sac", "humanoid", 1024), ("sac", "hopper", 64),
-                                        ("td3", "humanoid", 1024)])
+                                        ("td3", "humanoid", 1024), ("sac", "sac4", 128), ("td3", "td3_7", 300), ("td3", "td3_2", 64)])
 def test_period_graph_equals_single_iterations(algo, env, B):
     """sactd3_step_period (3 iterations of the schedule of orchestrator.py:345-349 in ONE graph: actor updates in the first,
     then two critic-only ones) == three sactd3_step calls, bit for bit; Engine.run_iterations mixes both forms around period
