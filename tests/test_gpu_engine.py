@@ -579,6 +579,23 @@ def test_graph_replay_equals_eager_launches(algo, env):
     assert outs[0][4] > 0 and outs[1][4] == 0
 
 
+@pytest.mark.parametrize("algo,env", [("sac", "hopper"), ("td3", "halfcheetah")])
+def test_period_and_cut_short_period_launch_sequences_equal_their_graphs(algo, env):
+    """use_graphs = 0 issues the very launch sequences the period / cut-short-period / opening graphs are captured from (chained
+    opening pairs included): 11 iterations through run_iterations -- singles, whole periods, a cut-short period -- are bit-identical
+    with and without hipGraphs."""
+    outs = []
+    for use_graphs in (True, False):
+        ref, eng, (o, a, bound) = make_pair(algo, env, 64, use_graphs=use_graphs, seed=3)
+        eng.rb_extend(*[t.numpy() for t in synth_transitions(700, o, a, bound, seed=22)])
+        assert eng.run_iterations(1, 10) == 11 and eng.run_iterations(11, 4) == 15     # 1, 2 | 3-5 | 6-8 | 9, 10 cut short ; 11 | 12-14
+        outs.append((eng.get_params(_lib.ACTOR), eng.get_params(_lib.CRITICS), eng.get_params(_lib.CRITICS_TARGET), eng.get_params(_lib.ACTOR_TARGET),
+                     eng.get_params(_lib.LOG_ALPHA), eng.read_batch()["index"], np.array(list(eng.read_metrics().values())), eng.graph_kernel_count(4)))
+    for x, y in zip(outs[0][:7], outs[1][:7]):
+        assert np.array_equal(x, y)
+    assert outs[0][7] > 0 and outs[1][7] == 0
+
+
 BASELINE_SHAPES = [("sac", "hopper", 256, 100_000), ("td3", "halfcheetah", 256, 100_000), ("sac", "humanoid", 1024, 65_536)]
 
 
