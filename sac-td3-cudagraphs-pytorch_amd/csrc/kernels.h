@@ -22,6 +22,10 @@
 //   k_actorq_tail     twin Q(s, pi(s)) -> min -> actor loss -> dQ routing -> head bwd -> LN bwd
 //   k_actor_head_bwd(_s)  d(action), d(logp) -> tanh-Gaussian bwd -> head bwd (MFMA; _s: DPP broadcast + FMAs) -> LN bwd
 //   k_ln_bwd          LN+ReLU backward of hidden layer 1 (+ the dQ/da slice product of the actor update)
+//   k_ctail_nn / k_qtail_nn / k_headbwd_nn   (B < 1024) a row kernel AND the dh1 = dz2 W2 GEMM behind it in one launch: every column-tile
+//                     block redoes the tail of its 16 rows; the epilogues leave what the next launch needs of layer 1's LayerNorm
+//                     backward (NnFold -> k_tn<.., true>) and of dQ/da (QaFold: per-tile partial sums by MFMA, finished in k_headbwd_nn)
+//   k_nt<.., C4>      32-row blocks with the summation tree of the 16-row form (bit-identical): the run-ahead launches of a period graph
 //   k_adam / k_polyak / k_alpha_step / k_gradnorm   flat optimiser kernels (stand-alone forms)
 // Riding blocks: launches carry independent work as extra blocks (replay gather, N(0,1) draws for the next tail, the previous
 // temperature step, target lerps, gradient finalisation) instead of paying a 2 us graph node for it.  Tile -> XCD placement: xcd_tile.
