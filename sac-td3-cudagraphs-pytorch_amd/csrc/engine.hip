@@ -417,6 +417,7 @@ static int launch_tn64(sactd3_engine* e, hipStream_t s, const char* name, const 
   return 0;
 }
 
+static inline int tn_width(const TnProb& q) { return q.kw > 0 ? q.kw : q.ldw; }
 static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& g, int nets, int tick_extra = 0) {
   if (g.M >= BIG_BATCH && e->Gp && !e->tune_tn_kt) {
     // the split-M form pays an extra node (k_adam_red): taken when the launch has enough 64 x 32 tiles to fill the chip with
@@ -429,7 +430,7 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
     int tiles = 0;
     for (int i = 0; i < g.nprob; ++i) {
       g.pr[i].tile0 = tiles;
-      tiles += ((g.pr[i].N + 15) / 16) * (((g.pr[i].ldw + 15) / 16 + kt - 1) / kt);
+      tiles += ((g.pr[i].N + 15) / 16) * (((tn_width(g.pr[i]) + 15) / 16 + kt - 1) / kt);
     }
     return tiles;
   };
@@ -439,13 +440,14 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
   if (e->tune_tn_kt) kt = e->tune_tn_kt;
   const int tiles = count(kt);
   for (int i = 0; i < g.nprob; ++i)      // n tiles need dY columns, k tiles X columns (both M rows long)
-    g.pr[i].xr = pick_xr(e, (g.pr[i].N + 15) / 16, ((g.pr[i].ldw + 15) / 16 + kt - 1) / kt, 4.0 * g.M * g.pr[i].N, 4.0 * g.M * g.pr[i].ldw);
+    g.pr[i].xr = g.pr[i].xr_force ? g.pr[i].xr_force
+                                  : pick_xr(e, (g.pr[i].N + 15) / 16, ((tn_width(g.pr[i]) + 15) / 16 + kt - 1) / kt, 4.0 * g.M * g.pr[i].N, 4.0 * g.M * tn_width(g.pr[i]));
   // dW = dY^T X of every problem; operands dY, X once each; the weight block's gradient written, and with the fused
   // optimiser step p, m, v read and written (+ the Polyak target): 4 (g) + 24 (Adam) + 8 (Polyak) bytes per parameter
   double fl = 0.0, by = 0.0;
   for (int i = 0; i < g.nprob; ++i) {
     fl += 2.0 * nets * (double)g.M * g.pr[i].N * g.pr[i].K;
-    by += 4.0 * nets * (double)g.M * (g.pr[i].N + (g.pr[i].x_dup ? 0 : g.pr[i].K)) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
+    by += 4.0 * nets * (double)g.M * ((g.pr[i].x_dup == 2 ? 0 : g.pr[i].N) + (g.pr[i].x_dup == 1 ? 0 : g.pr[i].K)) + (4.0 + (g.apply ? 24.0 : 0.0) + (g.apply && g.T ? 8.0 : 0.0)) * nets * (double)g.pr[i].N * (g.pr[i].K + 1);
   }
   bool fold = false;
   for (int i = 0; i < g.nprob; ++i) fold = fold || g.pr[i].fold;
@@ -470,7 +472,7 @@ static int launch_tn(sactd3_engine* e, hipStream_t s, const char* name, TnArgs& 
     r.loss_dst = g.loss_dst; r.tick = g.tick; r.tick_extra = tick_extra;
     g.fin_blocks = 4 * r.nvec + 1;
   }
-  const dim3 grid((unsigned)(tiles + g.pk_blocks + g.fin_blocks), 1, (unsigned)nets);
+  const dim3 grid((unsigned)((tiles + g.pk_blocks + g.fin_blocks + (nets > 1 ? 7 : 0)) & (nets > 1 ? ~7 : ~0)), 1, (unsigned)nets);
   if (!node_on(e, inst, fl, by, grid, dim3(256))) return 0;
   if (fold) {
     if (kt == 2) hipLaunchKernelGGL((k_tn<2, true>), grid, dim3(256), 0, s, g);
@@ -495,6 +497,16 @@ static TnProb tn_rows(const TnProb& q, int n_lo, int n) {
   TnProb r = q;
   r.dY = q.dY + n_lo; r.N = n; r.w_off = q.w_off + n_lo * q.ldw; r.b_off = q.b_off >= 0 ? q.b_off + n_lo : -1;
   if (n_lo) { r.nfin = 0; r.fin_s_off = -1; r.x_dup = 1; }
+  return r;
+}
+// Columns [k_lo, k_lo + k) of a weight-gradient problem as a problem of its own (cut along dW's COLUMNS: every piece has all of the
+// rows).  With xr_force = 8 the 8 XCDs each own two 16-row tiles of a piece -- the rows of W2 (and of its Polyak target) that the
+// next trunk launch reads on that very XCD (its column tile t = rows 32 t .. 32 t + 31 sits on XCD t mod 8): the optimiser epilogue
+// leaves them in the L2 that will want them.
+static TnProb tn_cols(const TnProb& q, int k_lo, int k) {
+  TnProb r = q;
+  r.X = q.X + k_lo; r.K = k; r.kw = k; r.w_off = q.w_off + k_lo;
+  if (k_lo) { r.b_off = -1; r.nfin = 0; r.fin_s_off = -1; r.x_dup = 2; }
   return r;
 }
 static void tn_fin(TnProb& q, int slot, int off, int nblk) { q.fin_slot[q.nfin] = slot; q.fin_off[q.nfin] = off; q.fin_nblk[q.nfin++] = nblk; }
@@ -847,7 +859,12 @@ static int enqueue_update_qnets(sactd3_engine* e, hipStream_t s, bool fused_samp
       TnProb& q = g.pr[i1];
       q.fold = 1; q.f_ln = ln; q.f_g_off = e->Lc.g1; q.f_be_off = e->Lc.be1; q.f_xh = e->c_xh1; q.f_rstd = e->c_rs1; q.f_ps = e->c_ps; q.f_dz = e->c_dz1; q.f_g = e->c_ps + 2L * B * PS_W;
     } else if (ln) { tn_fin(g.pr[i1], 3, e->Lc.g1, nb_ln); tn_fin(g.pr[i1], 4, e->Lc.be1, nb_ln); }
-    if (fold_ln1) { g.nprob = 3; g.pr[1] = tn_rows(g.pr[0], HID / 2, HID / 2); g.pr[0] = tn_rows(g.pr[0], 0, HID / 2); std::swap(g.pr[1], g.pr[2]); }
+    if (fold_ln1) {
+      g.nprob = 3;
+      if (e->tune_rows4 & 262144) { g.pr[1] = tn_rows(g.pr[0], HID / 2, HID / 2); g.pr[0] = tn_rows(g.pr[0], 0, HID / 2); }
+      else { g.pr[1] = tn_cols(g.pr[0], HID / 2, HID / 2); g.pr[0] = tn_cols(g.pr[0], 0, HID / 2); g.pr[0].xr_force = g.pr[1].xr_force = 8; }
+      std::swap(g.pr[1], g.pr[2]);
+    }
     g.part = e->part; g.pstride = e->nblk4; g.part_s = e->part_s;
     g.apply = 1; g.P = e->Pc; g.Mo = e->Mc; g.Vo = e->Vc; g.T = fused_polyak_targ; g.tau = c.polyak; g.adam = e->ctl->adam_q;
     g.b1 = c.adam_beta1; g.b2 = c.adam_beta2; g.eps = c.adam_eps;

@@ -1435,7 +1435,9 @@ struct TnProb {              // one weight-gradient GEMM: dW[N, ldw] = dY[M,N]^T
   // left them as one partial per 16-column tile (f_ps[net][row][0:16] = sum dy g, [16:32] = sum dy g xhat), summed here in
   // a fixed order.  The k-tile-0 blocks also own dgamma1 / dbeta1 of their 16 columns (column sums of dy xhat and dy over the
   // batch) and keep dz1 readable (f_dz).  f_ln == 0: no LayerNorm, dz1 = dy.
-  int x_dup;                             // host-side bookkeeping: a later row piece of a cut problem (tn_rows): its X operand is already counted
+  int x_dup;                             // host-side bookkeeping: a later piece of a cut problem: an operand that is already counted (1: X, 2: dY)
+  int xr_force;                          // host-side: placement chosen by the caller instead of pick_xr
+  int kw;                                // > 0: the problem is a COLUMN piece of a wider weight block (tn_cols): its width (ldw stays the row stride)
   int fold, f_ln, f_g_off, f_be_off;
   const float* f_xh; const float* f_rstd; const float* f_ps; float* f_dz;    // [nets][M][HID], [nets][M], [nets][M][32], [nets][M][HID]
   const float* f_g;                      // [nets][HID]: gamma1 as the producer saw it (the k-tile-0 blocks of THIS launch step the live one)
@@ -1506,8 +1508,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   if ((int)blockIdx.x >= p.tiles) {                         // (block-uniform) riding blocks
     const int x = (int)blockIdx.x - p.tiles;
     if (x < p.pk_blocks) { if (net == 0) polyak_body(p.pk, x, p.pk_blocks); }
-    else adam_red_tail_body(p.fin, x - p.pk_blocks, net);
-    BLK_MARK(1);
+    else if (x - p.pk_blocks < p.fin_blocks) adam_red_tail_body(p.fin, x - p.pk_blocks, net);      // (behind them: padding up to a multiple of 8 blocks
+    BLK_MARK(1);                                                                                  //  per net, so that every net's tile ids keep their XCDs)
     return;
   }
   int pi = 0;
@@ -1516,7 +1518,8 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   if (p.nprob > 3 && (int)blockIdx.x >= p.pr[3].tile0) pi = 3;
   const TnProb q = p.pr[pi];     // ONE batch of scalar loads for the whole problem (field-by-field they came in 3-4 dependent rounds)
   const int local = blockIdx.x - q.tile0;
-  const int tiles_k = (((q.ldw + 15) >> 4) + KT - 1) / KT;
+  const int kw = q.kw > 0 ? q.kw : q.ldw;                 // columns of this problem's piece of dW
+  const int tiles_k = (((kw + 15) >> 4) + KT - 1) / KT;
   int tn, tk;
   xcd_tile(local, (q.N + 15) >> 4, tiles_k, q.xr, tn, tk);
   const int n0 = tn * 16, k0 = tk * 16 * KT;
@@ -1561,7 +1564,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {          // clamped, not predicated (the commit is predicated)
       const int row = min(n0 + 4 * (lane >> 4) + i, q.N - 1);
-      st[i] = adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + min(ecol, q.ldw - 1));
+      st[i] = adam_fetch(p, nbase + q.w_off + (long)row * q.ldw + min(ecol, kw - 1));
     }
   }
   // k-tile-0 blocks also produce the bias gradient of their 16 columns (column sums of dY, collected from the LDS tile in the
@@ -1637,7 +1640,7 @@ __global__ __launch_bounds__(256) void k_tn(TnArgs p) {
   }
   __syncthreads();
   STAMP(3); BLK_PH(3);
-  if (wave < KT && ecol < q.ldw) {
+  if (wave < KT && ecol < kw) {
     const float* rr = red + (wave * 4 * 64 + lane) * 4;
     const float4 a = ld4(rr), b = ld4(rr + 256), c = ld4(rr + 512), d = ld4(rr + 768);
     const float o[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
